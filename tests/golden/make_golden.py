@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself (imported read-only from
+/root/reference, CPU, fp32).  Run in the authoring container only:
+
+    python tests/golden/make_golden.py
+
+Outputs (committed):
+  params_000007.npz        the reference checkpoint's tensors as float32 numpy (key names un-prefixed); the
+                           parity fixture weights for GPU-box tests, where /root/reference does not exist.
+  cascade_96x128_n2.npz    default config (iters 1,2,2; neighbours 0/8/16, 9/9/9), B=1, 2 source views: inputs,
+                           FeatureNet outputs, and every hot-path intermediate of every PatchMatch iteration,
+                           plus the final refined depth / confidence.
+  cascade_variant_b2.npz   B=2, 48x64, 3 source views, iters (2,1,1), propagate (4,8,16), evaluate (9,17,9): exercises
+                           the 4- and 17-neighbour tables, batch > 1 and propagation on stage 1.
+  ops_small.npz            differentiable_warping known answers incl. negative depth and src size != ref size.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import refutil  # noqa: E402
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def dump_cascade(path, model, n_views, H, W, B=1, seed=1234):
+    imgs = refutil.synthetic_images(n_views, H, W)
+    if B > 1:
+        imgs = [torch.cat([im, torch.flip(im, dims=[3])] + [im] * (B - 2), 0)[:B].contiguous() for im in imgs]
+    intr, extr = refutil.synthetic_cameras(n_views, H, W)
+    intr = np.repeat(intr, B, 0)
+    extr = np.repeat(extr, B, 0)
+    dmin = np.array([425.0, 400.0][:B], np.float32)
+    dmax = np.array([935.0, 900.0][:B], np.float32)
+    noise = torch.rand(B, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(seed))
+    depth, conf, dpm, tr = refutil.trace_reference_forward(
+        model, [i.clone() for i in imgs], torch.from_numpy(intr).clone(), torch.from_numpy(extr).clone(),
+        torch.from_numpy(dmin), torch.from_numpy(dmax), noise)
+    out = {"intrinsics": intr, "extrinsics": extr, "depth_min": dmin, "depth_max": dmax, "noise": t2n(noise),
+           "depth": t2n(depth), "confidence": t2n(conf), "n_views": np.int32(n_views)}
+    for v, im in enumerate(imgs):
+        out[f"image_{v}"] = t2n(im)
+    for v, f in enumerate(tr["features"]):
+        for s, x in f.items():
+            out[f"feature_{v}_s{s}"] = t2n(x)
+    for s in (1, 2, 3):
+        for k, x in tr[f"stage{s}"].items():
+            out[f"s{s}_{k}"] = t2n(x)
+        for it, rec in enumerate(tr[s]):
+            # (the [D,K,h,w] aggregation weights and the pre-softmax score are derivable and left out to keep
+            #  the fixtures small; the per-view similarity is kept for view 0 only)
+            for k in ("depth_sample", "similarity", "score", "view_weights", "depth"):
+                out[f"s{s}_it{it + 1}_{k}"] = t2n(rec[k])
+            for v, x in enumerate(rec["pixelwise_in"][:1]):
+                out[f"s{s}_it{it + 1}_view_similarity_{v}"] = t2n(x)
+        for it, d in enumerate(dpm[s]):
+            out[f"s{s}_it{it + 1}_depth_out"] = t2n(d)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+def dump_ops(path):
+    _, _, ref_module = refutil.import_reference()
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # case A: same size, some hypotheses behind the source camera (negative-depth sentinel)
+    # case B: source map smaller than the reference map
+    for name, (C, D, h, w, hs, ws) in {"A": (8, 5, 9, 11, 9, 11), "B": (4, 3, 10, 12, 7, 9)}.items():
+        src = torch.randn(2, C, hs, ws, generator=g)
+        f = 30.0
+        K = torch.tensor([[f, 0, w / 2, 0], [0, f, h / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+        a = 0.3
+        E = torch.eye(4)
+        E[:3, :3] = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        E[:3, 3] = torch.tensor([2.0, -1.0, -6.0])  # pushes near hypotheses behind the source camera
+        ref_proj = K.unsqueeze(0).repeat(2, 1, 1)
+        src_proj = (K @ E).unsqueeze(0).repeat(2, 1, 1)
+        src_proj[1, :3, 3] += torch.tensor([3.0, 2.0, 1.0])
+        depth = 2.0 + 10.0 * torch.rand(2, D, h, w, generator=g)
+        warped = ref_module.differentiable_warping(src, src_proj, ref_proj, depth)
+        out.update({f"{name}_src": t2n(src), f"{name}_src_proj": t2n(src_proj), f"{name}_ref_proj": t2n(ref_proj),
+                    f"{name}_depth": t2n(depth), f"{name}_warped": t2n(warped)})
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+def main():
+    assert refutil.have_reference(), "needs /root/reference"
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model = refutil.build_reference_model()
+    sd = refutil.state_dict_numpy(model)
+    p = os.path.join(HERE, "params_000007.npz")
+    np.savez_compressed(p, **sd)
+    print("wrote", p, "%.2f MB" % (os.path.getsize(p) / 1e6))
+    dump_cascade(os.path.join(HERE, "cascade_96x128_n2.npz"), model, 3, 96, 128)
+
+    # variant: non-default neighbour tables / iterations; weights = checkpoint where shapes agree, seeded random
+    # (small, so learned offsets stay sub-pixel..few-pixel) for the re-shaped offset heads.
+    ref_net, _, _ = refutil.import_reference()
+    variant = ref_net.PatchmatchNet(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+                                    patchmatch_iteration=[2, 1, 1], patchmatch_num_sample=[8, 8, 16],
+                                    propagate_neighbors=[4, 8, 16], evaluate_neighbors=[9, 17, 9])
+    base = refutil.load_reference_state_dict()
+    own = variant.state_dict()
+    g = torch.Generator().manual_seed(99)
+    for k, v in own.items():
+        if k in base and base[k].shape == v.shape:
+            own[k] = base[k].clone()
+        elif v.dtype.is_floating_point:
+            own[k] = 0.05 * torch.randn(v.shape, generator=g)
+    variant.load_state_dict(own)
+    variant.eval()
+    np.savez_compressed(os.path.join(HERE, "params_variant.npz"), **refutil.state_dict_numpy(variant))
+    dump_cascade(os.path.join(HERE, "cascade_variant_b2.npz"), variant, 4, 48, 64, B=2, seed=4321)
+    dump_ops(os.path.join(HERE, "ops_small.npz"))
+
+
+if __name__ == "__main__":
+    main()
