@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- depth-maps/sec of PatchmatchNet inference on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full ``PatchmatchNet.forward`` (FeatureNet on MIOpen, the learned-PatchMatch hot path in HIP, refinement,
+confidence) for ONE reference view with 5 source views at 1600x1200, iterations (1,2,2) -- BASELINE.json configs[1].
+Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU: reference views shard across ranks
+with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
+confidence maps closes the timed region, as the per-scan gather before fusion does in eval.
+
+Extra objects on the line: ``roofline`` for the dominant kernel (pmn_warp_correlate; HIP events on the launch stream
+inside the timed region; algorithmic bytes per SURVEY.md 8(d)) and, at N=1, ``cpu_baseline`` = the CPU oracle
+(oracle/, the checker -- never the thing shipped) timed on the host cores over one full-size hot-path pass.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+
+DEFAULT_KW = dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+                  patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[8, 8, 16], propagate_neighbors=[0, 8, 16],
+                  evaluate_neighbors=[9, 9, 9])
+
+
+def load_weights(model):
+    """Reference checkpoint tensors from the committed fixture; seeded random init if the fixture is unavailable."""
+    path = os.path.join(ROOT, "tests", "golden", "params_000007.npz")
+    if os.path.isfile(path):
+        with np.load(path) as z:
+            model.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=True)
+        return "params_000007 (reference checkpoint tensors)"
+    torch.manual_seed(0)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.ConvTranspose2d)):
+            torch.nn.init.kaiming_normal_(m.weight)
+    return "random init"
+
+
+def make_samples(n_samples, n_views, H, W, device, rank):
+    import synth
+    intr, extr = synth.synthetic_cameras(n_views, H, W)
+    samples = []
+    for s in range(n_samples):
+        g = torch.Generator().manual_seed(1000 * rank + s)
+        base = torch.rand(1, 3, H, W, generator=g)
+        base = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(base, (2, 2, 2, 2), mode="reflect"), 5, 1)
+        imgs = [(torch.roll(base, shifts=4 * v, dims=3) + 0.02 * torch.rand(1, 3, H, W, generator=g)).clamp(0, 1)
+                .contiguous().to(device) for v in range(n_views)]
+        samples.append(dict(images=imgs, intrinsics=torch.from_numpy(intr).to(device),
+                            extrinsics=torch.from_numpy(extr).to(device),
+                            depth_min=torch.tensor([425.0], device=device),
+                            depth_max=torch.tensor([935.0], device=device)))
+    return samples
+
+
+def cpu_baseline(H, W, n_src):
+    """The CPU oracle (a port of the reference arithmetic; oracle/) on one full-size hot-path pass: the cascade from
+    FeatureNet outputs to the stage-1 depth at 1600x1200, N=5, iterations (1,2,2)."""
+    import synth
+    from oracle import oracle as O
+    with np.load(os.path.join(ROOT, "tests", "golden", "params_000007.npz")) as z:
+        params = {k: z[k] for k in z.files}
+    f3 = synth.synthetic_features(n_src + 1, 64, H // 8, W // 8, 0)
+    f2 = synth.synthetic_features(n_src + 1, 32, H // 4, W // 4, 1)
+    f1 = synth.synthetic_features(n_src + 1, 16, H // 2, W // 2, 2)
+    feats = [{3: f3[i].numpy(), 2: f2[i].numpy(), 1: f1[i].numpy()} for i in range(n_src + 1)]
+    intr, extr = synth.synthetic_cameras(n_src + 1, H, W)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(1)).numpy()
+    cores = os.cpu_count() or 1
+    O.set_num_threads(cores)
+    t0 = time.perf_counter()
+    O.cascade(params, feats, intr, extr, np.array([425.0], np.float32), np.array([935.0], np.float32), noise)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+            "sample": f"1 hot-path pass (cascade stage3->1 from feature maps, FeatureNet/refinement excluded) at "
+                      f"{W}x{H}, N={n_src}, iters (1,2,2): {dt:.1f} s on {cores} threads (C oracle, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--height", type=int, default=1200)
+    ap.add_argument("--views", type=int, default=5, help="number of SOURCE views (reference eval.py --num_views)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import patchmatchnet_amd as P
+    from patchmatchnet_amd import ops
+    P.lib()  # fail loudly if the HIP library is missing
+
+    model = P.PatchmatchNet(**DEFAULT_KW)
+    weights = load_weights(model)
+    model = model.to(device).eval()
+    H, W, n_src = args.height, args.width, args.views
+    samples = make_samples(4, n_src + 1, H, W, device, rank)
+
+    def step(i):
+        s = samples[i % len(samples)]
+        return model([im for im in s["images"]], s["intrinsics"].clone(), s["extrinsics"], s["depth_min"],
+                     s["depth_max"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        ops.enable_kernel_timing()
+        t0 = time.perf_counter()
+        outs = None
+        for i in range(args.steps):
+            depth, conf, _ = step(i)
+            outs = (depth, conf)
+        if world > 1:
+            # per-scan gather of the final maps before fusion: the only collective of the path (RCCL over xGMI)
+            mine = torch.stack([outs[0][0, 0], outs[1][0]], 0).contiguous()
+            gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=device)
+            dist.all_gather_into_tensor(gathered, mine)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    recs = ops.disable_kernel_timing()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        k_ms = sum(r[0] for r in recs)
+        k_bytes = sum(r[1] for r in recs)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        per = {}
+        for ms, nb, tag in recs:
+            a = per.setdefault(tag, [0.0, 0, 0])
+            a[0] += ms
+            a[1] += nb
+            a[2] += 1
+        line = {
+            "metric": "depth-maps/sec at 1600x1200 N=5 src views", "value": round(value, 4), "unit": "depth-maps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
+                                   f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
+                       "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence"},
+            "roofline": {"bound": "hbm", "kernel": "gather_corr_kernel (pmn_warp_correlate)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launches": len(recs), "kernel_ms_per_step": round(k_ms / args.steps, 4),
+                         "alg_bytes_per_step": int(k_bytes / args.steps),
+                         "per_shape": {k: {"ms_avg": round(v[0] / v[2], 4),
+                                           "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0.0}
+                                       for k, v in per.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(H, W, n_src)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+/*
+ * pmn_hip.h -- C ABI of libpmn_hip.so: the MI355X (gfx950) kernels behind PatchmatchNet's learned-PatchMatch
+ * hot path.  This is the drop-in boundary: plain pointers and sizes, no torch types.
+ *
+ * The reference (FangjinhuaWang/PatchmatchNet) is pure Python over PyTorch and has no FFI of its own; each entry
+ * point below replaces the PyTorch op sequence at the cited reference lines.  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add to models/patchmatch.py / models/module.py.
+ *
+ * Contract common to every entry point
+ *   - all tensor arguments are DEVICE pointers to contiguous float32 buffers owned (and pre-allocated) by the
+ *     caller; the library never allocates, never synchronises, and launches on `stream` (a hipStream_t; pass the
+ *     caller's current stream, NULL = default stream);
+ *   - arguments documented "host" (*_host) are small HOST arrays copied into the kernel-argument segment;
+ *   - returns PMN_OK (0) or a negative PMN_ERR_* code; nothing is launched when an argument check fails;
+ *   - one process drives one GPU; entry points are re-entrant and keep no global state.
+ *
+ * Layouts
+ *   feature maps    channels-last  [B, h, w, C]           (source views stacked: [N, B, hs, ws, C])
+ *   hypotheses      [B, D, h, w]   (D <= PMN_MAX_DEPTH)   depth_sample of the reference
+ *   per-view weight [B, N, h, w]
+ *   offsets         [B, 2K, h, w]  output of the reference's propa_conv / eval_conv (channel 2k -> x, 2k+1 -> y)
+ *   neighbour table host int[2K]   (dy,dx) pairs, reference models/patchmatch.py:331-392
+ *   MLP block       host float[PMN_MLP_FLOATS]: w0[16][8] (row j holds G used entries, BN folded), t0[16],
+ *                   w1[8][16] (BN folded), t1[8], w2[8], b2   -- see patchmatchnet_amd/params.py
+ */
+#ifndef PMN_HIP_H
+#define PMN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMN_ABI_VERSION 1
+#define PMN_MLP_FLOATS 289
+#define PMN_MAX_DEPTH 64
+#define PMN_MAX_NEIGHBORS 17
+
+#define PMN_OK 0
+#define PMN_ERR_ARG (-1)     /* null pointer / size out of range */
+#define PMN_ERR_SHAPE (-2)   /* unsupported channel / group / neighbour / hypothesis count */
+#define PMN_ERR_LAUNCH (-3)  /* hipGetLastError() after the launch */
+
+/* ABI version of the loaded library (== PMN_ABI_VERSION of the header it was built from). */
+int pmn_abi_version(void);
+
+/* Human-readable text for a PMN_ERR_* code. */
+const char *pmn_error_string(int code);
+
+/* [B,C,h,w] -> [B,h,w,C].  Feeds FeatureNet outputs (reference models/net.py:203-208) to the kernels below.
+ * `out` may be a slot of the stacked source buffer. */
+int pmn_nchw_to_nhwc(const float *in, float *out, int B, int C, int h, int w, void *stream);
+
+/* FeatureWeightNet.forward (reference models/patchmatch.py:603-624) fused with get_grid (:396-426):
+ * gather the K evaluation neighbours of every reference pixel (bilinear, border, align_corners=False on a grid
+ * normalised with (size-1)/2), group-wise correlation with the centre feature, MLP, sigmoid.
+ * out_feature_weight [B,K,h,w].  C in {16,32,64}, G in {4,8} with C/G in {4,8}, K in {9,17}. */
+int pmn_feature_weight(const float *ref_nhwc, const float *eval_offsets, const int *eval_table_host,
+                       const float *mlp_host, int B, int C, int G, int K, int h, int w,
+                       float *out_feature_weight, void *stream);
+
+/* DepthInitialization.forward + Propagation.forward (reference models/patchmatch.py:53-94, 115-124), fused:
+ *   noise != NULL : first iteration on the coarsest stage; 48 hypotheses from the caller's torch.rand draw
+ *                   noise [B,48,h,w] (the RNG stays with the caller so it matches the reference stream);
+ *   noise == NULL : num_sample hypotheses around `depth` ([B,1,h>>depth_shift,w>>depth_shift]; depth_shift=1
+ *                   reads the previous stage's map through the nearest x2 up-sampling of net.py:274);
+ *                   num_sample == 1 passes depth through.
+ *   K > 0         : the centre hypothesis (index D0/2) is gathered at the K propagation neighbours, appended, and
+ *                   the D = D0 + K values are sorted ascending per pixel.
+ * depth_min/depth_max: device float[B].  Outputs: depth_sample [B,D,h,w] and its normalised inverse depth
+ * xnorm [B,D,h,w] = (1/d - 1/dmax)/(1/dmin - 1/dmax) (reference :655-657), used by pmn_aggregate_regress. */
+int pmn_init_hypotheses(const float *noise, const float *depth, int depth_shift, const float *depth_min,
+                        const float *depth_max, int num_sample, float interval_scale, const float *propa_offsets,
+                        const int *propa_table_host, int K, int B, int h, int w, float *depth_sample,
+                        float *xnorm, void *stream);
+
+/* The fused hot kernel.  Evaluation.forward up to and including SimilarityNet's pointwise MLP
+ * (reference models/patchmatch.py:192-217, 570; differentiable_warping models/module.py:130-181;
+ * PixelwiseNet :695-702):  for every source view: homography warp of the D hypotheses, bilinear (zeros,
+ * align_corners=True) gather of the source features, group-wise correlation with the reference feature;
+ * view weights either read from view_weights_in ([B,N,h>>vw_shift,w>>vw_shift]; vw_shift = 1 / 2 reads a
+ * coarser stage's map through the nearest x2 / x4 up-sampling of net.py:275) or -- view_weights_in == NULL -- computed by PixelwiseNet (max over D of the
+ * sigmoid response) and written to view_weights_out [B,N,h,w] (+ optional arg-max index vw_argmax_out);
+ * weighted aggregation over views; SimilarityNet MLP -> cost_out [B,D,h,w].
+ * rel_proj [B,N,4,4] = src_proj @ inverse(ref_proj).  similarity_out (optional) receives the aggregated
+ * similarity [B,G,D,h,w] (the tensor the reference materialises at :217).
+ * The warped volume [B,C,D,h,w] is never materialised. */
+int pmn_warp_correlate(const float *ref_nhwc, const float *src_nhwc, const float *rel_proj,
+                       const float *depth_sample, const float *view_weights_in, int vw_shift,
+                       const float *similarity_mlp_host, const float *pixelwise_mlp_host, int B, int N, int C,
+                       int G, int D, int h, int w, int hs, int ws, float *cost_out, float *view_weights_out,
+                       int *vw_argmax_out, float *similarity_out, void *stream);
+
+/* Adaptive spatial cost aggregation + softmax + regression: depth_weight (reference models/patchmatch.py:650-669),
+ * weight normalisation (:509-510), SimilarityNet's neighbour gather and weighted sum (:569-577),
+ * exp(log_softmax) (:221) and depth regression (:226-237).
+ * score_out [B,D,h,w] = probabilities, depth_out [B,h,w].  is_inverse selects the inverse-depth regression. */
+int pmn_aggregate_regress(const float *cost, const float *depth_sample, const float *xnorm,
+                          const float *feature_weight, const float *eval_offsets, const int *eval_table_host,
+                          int K, float interval_scale, int is_inverse, int B, int D, int h, int w,
+                          float *score_out, float *depth_out, void *stream);
+
+/* Photometric-confidence epilogue (reference models/net.py:288-299): 4-wide window sum of the stage-1
+ * probabilities around trunc(sum_d d*p_d), nearest resize to [B,H,W].  depth_index_out (optional) [B,h,w]. */
+int pmn_confidence(const float *score, int B, int D, int h, int w, int H, int W, float *confidence_out,
+                   int *depth_index_out, void *stream);
+
+/* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
+ * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */
+int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, const float *depth, int B, int C,
+                               int D, int h, int w, int hs, int ws, float *warped, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMN_HIP_H */

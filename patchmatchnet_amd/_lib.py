@@ -1,0 +1,81 @@
+"""ctypes binding of libpmn_hip.so (C ABI declared in include/pmn_hip.h).
+
+The library is built in-tree (``patchmatchnet_amd/csrc/libpmn_hip.so``) by ``build()`` / ``make -C patchmatchnet_amd/csrc``
+so that it travels with the source snapshot.  There is no fallback: if the library is missing or a symbol is absent
+the product raises, it never silently runs something else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
+ABI_VERSION = 1
+MLP_FLOATS = 289
+MAX_DEPTH = 64
+MAX_NEIGHBORS = 17
+
+_fp = ctypes.c_void_p  # device float* (passed as integer address)
+_ip = ctypes.c_void_p
+_hp = ctypes.c_void_p  # host pointer
+_i = ctypes.c_int
+_f = ctypes.c_float
+_s = ctypes.c_void_p   # hipStream_t
+
+# name -> argtypes; mirrors include/pmn_hip.h one to one (tests/test_abi.py checks the header against this table)
+SIGNATURES = {
+    "pmn_abi_version": [],
+    "pmn_error_string": [_i],
+    "pmn_nchw_to_nhwc": [_fp, _fp, _i, _i, _i, _i, _s],
+    "pmn_feature_weight": [_fp, _fp, _hp, _hp, _i, _i, _i, _i, _i, _i, _fp, _s],
+    "pmn_init_hypotheses": [_fp, _fp, _i, _fp, _fp, _i, _f, _fp, _hp, _i, _i, _i, _i, _fp, _fp, _s],
+    "pmn_warp_correlate": [_fp, _fp, _fp, _fp, _fp, _i, _hp, _hp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _ip,
+                           _fp, _s],
+    "pmn_aggregate_regress": [_fp, _fp, _fp, _fp, _fp, _hp, _i, _f, _i, _i, _i, _i, _i, _fp, _fp, _s],
+    "pmn_confidence": [_fp, _i, _i, _i, _i, _i, _i, _fp, _ip, _s],
+    "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
+}
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+class PmnError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j4"] + (["-B"] if force else [])
+    if not verbose:
+        args.insert(1, "-s")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libpmn_hip.so; raises PmnError when it is missing (the product has no other compute path)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise PmnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C patchmatchnet_amd/csrc` -- patchmatchnet_amd has no fallback path")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise PmnError(f"libpmn_hip.so does not export {name}") from e
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "pmn_error_string" else ctypes.c_int
+        if L.pmn_abi_version() != ABI_VERSION:
+            raise PmnError(f"libpmn_hip.so ABI {L.pmn_abi_version()} != expected {ABI_VERSION}: rebuild")
+        _LIB = L
+    return _LIB
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise PmnError(f"{what} failed: {lib().pmn_error_string(code).decode()} (code {code})")

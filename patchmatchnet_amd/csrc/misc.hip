@@ -1,0 +1,108 @@
+// misc.hip -- layout change, confidence epilogue, stand-alone warping op, ABI housekeeping.
+#include <cstring>
+
+#include "pmn_common.hpp"
+
+extern "C" int pmn_abi_version(void) { return PMN_ABI_VERSION; }
+
+extern "C" const char* pmn_error_string(int code) {
+    switch (code) {
+        case PMN_OK: return "ok";
+        case PMN_ERR_ARG: return "invalid argument (null pointer or size out of range)";
+        case PMN_ERR_SHAPE: return "unsupported shape (channels/groups/neighbours/hypotheses)";
+        case PMN_ERR_LAUNCH: return "HIP launch failed";
+        default: return "unknown error";
+    }
+}
+
+// ---- NCHW -> NHWC ------------------------------------------------------------------------------------------------
+// 64-pixel x C-channel tile through LDS: reads coalesced along pixels, writes coalesced along channels.
+__global__ __launch_bounds__(PMN_BLOCK) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int C, int hw) {
+    extern __shared__ float tile[];  // [C][65]
+    const int b = blockIdx.y, p0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int idx = tid; idx < C * 64; idx += PMN_BLOCK) {
+        const int c = idx >> 6, i = idx & 63;
+        tile[c * 65 + i] = (p0 + i < hw) ? in[((size_t)b * C + c) * hw + p0 + i] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < C * 64; idx += PMN_BLOCK) {
+        const int i = idx / C, c = idx - i * C;
+        if (p0 + i < hw) out[((size_t)b * hw + p0 + i) * C + c] = tile[c * 65 + i];
+    }
+}
+
+extern "C" int pmn_nchw_to_nhwc(const float* in, float* out, int B, int C, int h, int w, void* stream) {
+    if (!in || !out || B < 1 || C < 1 || h < 1 || w < 1) return PMN_ERR_ARG;
+    if (C > 128) return PMN_ERR_SHAPE;
+    const int hw = h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((hw + 63) / 64, B), dim3(PMN_BLOCK), (size_t)C * 65 * sizeof(float),
+                       (hipStream_t)stream, in, out, C, hw);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// ---- confidence epilogue (reference models/net.py:288-299, models/module.py:184-196) ---------------------------------
+__global__ __launch_bounds__(PMN_BLOCK) void confidence_kernel(const float* __restrict__ score, int D, int h, int w, int H,
+                                                              int W, float* __restrict__ conf, int* __restrict__ dindex) {
+#pragma clang fp contract(off)
+    const int q = blockIdx.x * PMN_BLOCK + threadIdx.x, b = blockIdx.y;
+    if (q >= H * W) return;
+    const int Y = q / W, X = q - Y * W;
+    // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out)), in-1), scale in fp32
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int y = min((int)floorf((float)Y * sy), h - 1);
+    const int x = min((int)floorf((float)X * sx), w - 1);
+    const size_t hw = (size_t)h * w;
+    const float* sp = score + (size_t)b * D * hw + (size_t)y * w + x;
+    float idxf = 0.0f;
+    for (int d = 0; d < D; ++d) idxf = idxf + sp[d * hw] * (float)d;
+    int idx = (int)idxf;  // .long(): truncation
+    idx = min(max(idx, 0), D - 1);
+    // 4 * avg_pool3d over the zero-padded (1 front, 2 back) volume = sum of p[idx-1 .. idx+2]
+    float s = 0.0f;
+    for (int j = idx - 1; j <= idx + 2; ++j) s = s + ((j >= 0 && j < D) ? sp[j * hw] : 0.0f);
+    s = s / 4.0f * 4.0f;
+    conf[(size_t)b * H * W + q] = s;
+    // every output pixel mapped onto (y,x) computes the same index; the duplicate stores are benign
+    if (dindex) dindex[(size_t)b * hw + (size_t)y * w + x] = idx;
+}
+
+extern "C" int pmn_confidence(const float* score, int B, int D, int h, int w, int H, int W, float* confidence_out,
+                              int* depth_index_out, void* stream) {
+    if (!score || !confidence_out || B < 1 || D < 1 || h < 1 || w < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    hipLaunchKernelGGL(confidence_kernel, dim3((H * W + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+                       (hipStream_t)stream, score, D, h, w, H, W, confidence_out, depth_index_out);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// ---- stand-alone differentiable_warping (reference models/module.py:130-181) ---------------------------------------
+__global__ __launch_bounds__(PMN_BLOCK) void warping_kernel(const float* __restrict__ src, const float* __restrict__ proj,
+                                                           const float* __restrict__ depth, int C, int D, int h, int w,
+                                                           int hs, int ws, float* __restrict__ warped) {
+    const int hw = h * w;
+    const int i = blockIdx.x * PMN_BLOCK + threadIdx.x, b = blockIdx.y;
+    if (i >= D * hw) return;
+    const int d = i / hw, p = i - d * hw, y = p / w, x = p - y * w;
+    float ix, iy;
+    pmn_warp_position(proj + (size_t)b * 16, (float)x, (float)y, depth[((size_t)b * D + d) * hw + p], h, w, hs, ws, ix,
+                      iy);
+    const PmnTaps t = pmn_make_taps(ix, iy, hs, ws);
+    const float* sp = src + (size_t)b * C * hs * ws + t.off;
+    for (int c = 0; c < C; ++c) {
+        const float* q = sp + (size_t)c * hs * ws;
+        const float v = fmaf(q[ws + 1], t.w11, fmaf(q[ws], t.w10, fmaf(q[1], t.w01, q[0] * t.w00)));
+        warped[(((size_t)b * C + c) * D + d) * hw + p] = v;
+    }
+}
+
+extern "C" int pmn_differentiable_warping(const float* src_nchw, const float* rel_proj, const float* depth, int B, int C,
+                                          int D, int h, int w, int hs, int ws, float* warped, void* stream) {
+    if (!src_nchw || !rel_proj || !depth || !warped) return PMN_ERR_ARG;
+    if (B < 1 || C < 1 || D < 1 || h < 2 || w < 2 || hs < 2 || ws < 2) return PMN_ERR_ARG;
+    hipLaunchKernelGGL(warping_kernel, dim3((D * h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+                       (hipStream_t)stream, src_nchw, rel_proj, depth, C, D, h, w, hs, ws, warped);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

@@ -1,0 +1,167 @@
+// Shared device helpers for the PatchmatchNet MI355X (gfx950) kernels.
+//
+// Arithmetic conventions (parity with the PyTorch ops the reference calls):
+//  * coordinate maths is compiled under `#pragma clang fp contract(off)` so hipcc does not contract it into
+//    FMAs -- the reference materialises every intermediate tensor (one rounding per op), and bit-identical
+//    sample positions make the tap sets identical to the oracle's;
+//  * divisions are IEEE (hipcc default: correctly rounded fp32 divide);
+//  * bilinear taps follow ATen's grid_sampler_2d: corner weights (x1-ix)*(y1-iy) ..., corners accumulated in
+//    the order nw, ne, sw, se, out-of-range corners contribute nothing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pmn_hip.h"
+
+#define PMN_BLOCK 256
+
+// ---- pointwise MLP G -> 16 -> 8 -> 1 (ConvBnReLU3D x2 + Conv3d; reference models/module.py:43-72) ----------
+// BatchNorm (eval) is folded on the host in fp64: w' = w * gamma/sqrt(var+eps), t = beta - mean*gamma/sqrt(var+eps).
+// The struct travels in the kernarg segment, so the weights are scalar loads / SGPR operands.
+struct PmnMlp {
+    float w0[16 * 8];  // [16][G] row-major, only the first 16*G entries used
+    float t0[16];
+    float w1[8 * 16];
+    float t1[8];
+    float w2[8];
+    float b2;
+};
+static_assert(sizeof(PmnMlp) == PMN_MLP_FLOATS * sizeof(float), "host/device MLP packing mismatch");
+
+template <int G>
+__device__ __forceinline__ float pmn_mlp_eval(const PmnMlp& P, const float (&x)[G]) {
+    float h0[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float acc = P.w0[j * G] * x[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) acc = fmaf(P.w0[j * G + g], x[g], acc);
+        acc += P.t0[j];
+        h0[j] = fmaxf(acc, 0.0f);
+    }
+    float h1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float acc = P.w1[j * 16] * h0[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) acc = fmaf(P.w1[j * 16 + i], h0[i], acc);
+        acc += P.t1[j];
+        h1[j] = fmaxf(acc, 0.0f);
+    }
+    float acc = P.w2[0] * h1[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) acc = fmaf(P.w2[i], h1[i], acc);
+    return acc + P.b2;
+}
+
+__device__ __forceinline__ float pmn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- bilinear tap set --------------------------------------------------------------------------------------
+// Texel index of the (clamped) north-west corner plus the weights of the 2x2 block anchored there.  Corners that
+// ATen would skip as out of range get weight 0 and a clamped (always legal) address; when the true NW corner is
+// at -1 (or the true SE corner at `size`) the surviving weights are moved onto the clamped block so every
+// in-range corner keeps exactly the weight ATen gives it, in the same nw,ne,sw,se order.
+struct PmnTaps {
+    int off;                   // y0c * ws + x0c
+    float w00, w01, w10, w11;  // weights of (y0c,x0c) (y0c,x0c+1) (y0c+1,x0c) (y0c+1,x0c+1)
+};
+
+__device__ __forceinline__ void pmn_axis(float pos, int size, int& i0c, float& wa, float& wb) {
+#pragma clang fp contract(off)
+    float f0 = floorf(pos);
+    float f1 = f0 + 1.0f;
+    float w_lo = f1 - pos;  // weight of the low (west / north) corner
+    float w_hi = pos - f0;  // weight of the high (east / south) corner
+    // clamp before the int conversion so wild coordinates cannot overflow
+    int i0 = (int)fminf(fmaxf(f0, -2.0f), (float)size);
+    i0c = min(max(i0, 0), size - 2);
+    wa = 0.0f;
+    wb = 0.0f;
+    if (i0 == i0c) {  // both corners addressable at their natural slots (hi corner may still be == size-1)
+        wa = w_lo;
+        wb = w_hi;
+    } else if (i0 == -1) {  // low corner out of range; hi corner is texel 0 = slot a
+        wa = w_hi;
+    } else if (i0 == size - 1) {  // hi corner out of range; low corner is texel size-1 = slot b
+        wb = w_lo;
+    }
+}
+
+__device__ __forceinline__ PmnTaps pmn_make_taps(float ix, float iy, int hs, int ws) {
+#pragma clang fp contract(off)
+    int x0c, y0c;
+    float ax, bx, ay, by;
+    pmn_axis(ix, ws, x0c, ax, bx);
+    pmn_axis(iy, hs, y0c, ay, by);
+    PmnTaps t;
+    t.off = y0c * ws + x0c;
+    t.w00 = ax * ay;
+    t.w01 = bx * ay;
+    t.w10 = ax * by;
+    t.w11 = bx * by;
+    return t;
+}
+
+// ---- sample positions ---------------------------------------------------------------------------------------
+
+// F.grid_sample un-normalisation (ATen grid_sampler_unnormalize)
+__device__ __forceinline__ float pmn_unnorm_align(float c, int size) {
+#pragma clang fp contract(off)
+    return ((c + 1.0f) / 2.0f) * (float)(size - 1);
+}
+__device__ __forceinline__ float pmn_unnorm_noalign(float c, int size) {
+#pragma clang fp contract(off)
+    return ((c + 1.0f) * (float)size - 1.0f) / 2.0f;
+}
+
+// Homography warp of reference pixel (x,y) at depth d into the source map (reference models/module.py:161-181).
+// P = relative projection src_proj @ inv(ref_proj), row-major 4x4.
+__device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, float x, float y, float d, int h,
+                                                  int w, int hs, int ws, float& ix, float& iy) {
+#pragma clang fp contract(off)
+    float rx = (P[0] * x + P[1] * y) + P[2];
+    float ry = (P[4] * x + P[5] * y) + P[6];
+    float rz = (P[8] * x + P[9] * y) + P[10];
+    float px = rx * d + P[3];
+    float py = ry * d + P[7];
+    float pz = rz * d + P[11];
+    if (pz <= 1e-3f) {  // behind / on the source camera: (w, h, 1) lands outside every tap
+        px = (float)w;
+        py = (float)h;
+        pz = 1.0f;
+    }
+    float gx = px / pz, gy = py / pz;
+    float xn = gx / ((float)(w - 1) / 2.0f) - 1.0f;
+    float yn = gy / ((float)(h - 1) / 2.0f) - 1.0f;
+    ix = pmn_unnorm_align(xn, ws);
+    iy = pmn_unnorm_align(yn, hs);
+}
+
+// Neighbour k of pixel (x,y): fixed table offset + learned offset, normalised with (size-1)/2 (get_grid,
+// reference models/patchmatch.py:409-421) but sampled with align_corners=False + border clip.
+__device__ __forceinline__ void pmn_neighbor_position(float x, float y, int dy, int dx, float offx, float offy,
+                                                      int h, int w, float& ix, float& iy) {
+#pragma clang fp contract(off)
+    float X = x + ((float)dx + offx);
+    float Y = y + ((float)dy + offy);
+    float xn = X / ((float)(w - 1) / 2.0f) - 1.0f;
+    float yn = Y / ((float)(h - 1) / 2.0f) - 1.0f;
+    ix = fminf(fmaxf(pmn_unnorm_noalign(xn, w), 0.0f), (float)(w - 1));
+    iy = fminf(fmaxf(pmn_unnorm_noalign(yn, h), 0.0f), (float)(h - 1));
+}
+
+// XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of tiles so
+// neighbouring tiles (which share source texels) hit the same private L2.  Bijective for any tile count.
+__device__ __forceinline__ int pmn_xcd_tile(int bid, int ntiles) {
+    const int NX = 8;
+    int per = ntiles / NX, rem = ntiles % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    // XCDs [0, rem) own (per+1) tiles, the rest own `per`
+    return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+}
+
+#define PMN_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) return PMN_ERR_LAUNCH;        \
+    } while (0)

@@ -1,0 +1,197 @@
+"""PatchmatchNet cascade on MI355X: the outer drop-in boundary (mirror of the reference's ``models/net.py`` interface).
+
+``PatchmatchNet(...)`` takes the reference's constructor arguments, exposes the same sub-module / state-dict names
+(``feature``, ``patchmatch_1..3``, ``upsample_net``) and ``forward`` returns the same triple.  FeatureNet and Refinement
+stay ordinary PyTorch-ROCm modules (MIOpen); everything between them runs in the HIP kernels of
+``patchmatchnet_amd/csrc`` -- there is no CPU / eager fallback for that part.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import PmnError
+from .module import ConvBnReLU
+from .patchmatch import PatchMatch
+
+
+class FeatureNet(nn.Module):
+    """FPN feature extractor (reference models/net.py:9-70); outputs {3: [B,64,H/8,W/8], 2: [B,32,H/4,W/4],
+    1: [B,16,H/2,W/2]}.  Kept on PyTorch-ROCm."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        spec = [(3, 8, 3, 1, 1), (8, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 16, 3, 1, 1), (16, 16, 3, 1, 1),
+                (16, 32, 5, 2, 2), (32, 32, 3, 1, 1), (32, 32, 3, 1, 1), (32, 64, 5, 2, 2), (64, 64, 3, 1, 1),
+                (64, 64, 3, 1, 1)]
+        for i, (cin, cout, k, s, p) in enumerate(spec):
+            setattr(self, f"conv{i}", ConvBnReLU(cin, cout, k, s, p))
+        self.output1 = nn.Conv2d(64, 64, 1, bias=False)
+        self.inner1 = nn.Conv2d(32, 64, 1, bias=True)
+        self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
+        self.output2 = nn.Conv2d(64, 32, 1, bias=False)
+        self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+
+    def forward(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
+        half = self.conv4(self.conv3(self.conv2(self.conv1(self.conv0(x)))))
+        quarter = self.conv7(self.conv6(self.conv5(half)))
+        eighth = self.conv10(self.conv9(self.conv8(quarter)))
+        out: Dict[int, torch.Tensor] = {3: self.output1(eighth)}
+        top = F.interpolate(eighth, scale_factor=2.0, mode="bilinear", align_corners=False) + self.inner1(quarter)
+        out[2] = self.output2(top)
+        top = F.interpolate(top, scale_factor=2.0, mode="bilinear", align_corners=False) + self.inner2(half)
+        out[1] = self.output3(top)
+        return out
+
+
+class Refinement(nn.Module):
+    """Depth-residual refinement at full resolution (reference models/net.py:73-122).  Kept on PyTorch-ROCm."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.conv0 = ConvBnReLU(in_channels=3, out_channels=8)
+        self.conv1 = ConvBnReLU(in_channels=1, out_channels=8)
+        self.conv2 = ConvBnReLU(in_channels=8, out_channels=8)
+        self.deconv = nn.ConvTranspose2d(8, 8, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False)
+        self.bn = nn.BatchNorm2d(8)
+        self.conv3 = ConvBnReLU(in_channels=16, out_channels=8)
+        self.res = nn.Conv2d(8, 1, kernel_size=3, padding=1, bias=False)
+
+    def forward(self, img: torch.Tensor, depth_0: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor
+                ) -> torch.Tensor:
+        b = depth_min.size()[0]
+        lo = depth_min.view(b, 1, 1, 1)
+        span = (depth_max - depth_min).view(b, 1, 1, 1)
+        d = (depth_0 - lo) / span
+        img_feat = self.conv0(img)
+        up = F.relu(self.bn(self.deconv(self.conv2(self.conv1(d)))), inplace=True)
+        res = self.res(self.conv3(torch.cat((up, img_feat), dim=1)))
+        d = F.interpolate(d, scale_factor=2.0, mode="nearest") + res
+        return d * span + lo
+
+
+class PatchmatchNet(nn.Module):
+    """Coarse-to-fine learned PatchMatch MVS network; interface of reference models/net.py:125-301."""
+
+    def __init__(self, patchmatch_interval_scale: List[float], propagation_range: List[int],
+                 patchmatch_iteration: List[int], patchmatch_num_sample: List[int], propagate_neighbors: List[int],
+                 evaluate_neighbors: List[int]) -> None:
+        super().__init__()
+        self.stages = 4
+        self.feature = FeatureNet()
+        self.patchmatch_num_sample = patchmatch_num_sample
+        num_features = [16, 32, 64]
+        self.propagate_neighbors = propagate_neighbors
+        self.evaluate_neighbors = evaluate_neighbors
+        self.G = [4, 8, 8]
+        for i in range(self.stages - 1):
+            setattr(self, f"patchmatch_{i + 1}", PatchMatch(
+                propagation_out_range=propagation_range[i], patchmatch_iteration=patchmatch_iteration[i],
+                patchmatch_num_sample=patchmatch_num_sample[i], patchmatch_interval_scale=patchmatch_interval_scale[i],
+                num_feature=num_features[i], G=self.G[i], propagate_neighbors=self.propagate_neighbors[i],
+                evaluate_neighbors=evaluate_neighbors[i], stage=i + 1))
+        self.upsample_net = Refinement()
+        # Run FeatureNet once on the N+1 images stacked along the batch axis when they share a size (same per-sample
+        # arithmetic, N+1 times fewer launches).  Set False to mirror the reference's per-image loop exactly.
+        self.batch_feature_extraction = True
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts both plain and ``module.``-prefixed (nn.DataParallel) checkpoints (reference eval.py:33-35)."""
+        if any(k.startswith("module.") for k in state_dict):
+            state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def extract_features(self, images: List[torch.Tensor]) -> List[Dict[int, torch.Tensor]]:
+        same = all(im.shape == images[0].shape for im in images)
+        if self.batch_feature_extraction and same and len(images) > 1:
+            B = images[0].shape[0]
+            f = self.feature(torch.cat(images, dim=0))
+            return [{s: t[i * B:(i + 1) * B] for s, t in f.items()} for i in range(len(images))]
+        return [self.feature(im) for im in images]
+
+    def forward(self, images: List[torch.Tensor], intrinsics: torch.Tensor, extrinsics: torch.Tensor,
+                depth_min: torch.Tensor, depth_max: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                features: Optional[List[Dict[int, torch.Tensor]]] = None, debug: Optional[dict] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor, Dict[int, List[torch.Tensor]]]:
+        """Reference arguments (images: N x [B,3,H,W]; intrinsics [B,N,3,3]; extrinsics [B,N,4,4]; depth_min/max [B]).
+
+        Optional extras (default = reference behaviour): ``noise`` [B,48,H/8,W/8] pins the stage-3 random draw,
+        ``features`` injects pre-computed FeatureNet outputs, ``debug`` (dict) collects per-stage intermediates.
+        Returns (depth [B,1,H,W], photometric confidence [B,H,W] (empty in training mode), {stage: [depths]})."""
+        assert len(images) == intrinsics.size()[1], "Different number of images and intrinsic matrices"
+        assert len(images) == extrinsics.size()[1], "Different number of images and extrinsic matrices"
+        if self.training:
+            raise PmnError("patchmatchnet_amd.PatchmatchNet is inference-only: call .eval() (the HIP kernels have no "
+                           "backward pass)")
+        images, intrinsics, orig_height, orig_width = adjust_image_dims(images, intrinsics)
+        ref_image = images[0]
+        _, _, ref_height, ref_width = ref_image.size()
+
+        if features is None:
+            features = self.extract_features(images)
+        ref_feature, src_features = features[0], features[1:]
+
+        depth_min = depth_min.float()
+        depth_max = depth_max.float()
+        device = intrinsics.device
+        depth = torch.empty(0, device=device)
+        score = torch.empty(0, device=device)
+        view_weights = torch.empty(0, device=device)
+        depth_patchmatch: Dict[int, List[torch.Tensor]] = {}
+
+        scale = 0.125
+        depth_shift, vw_shift = 0, 0
+        for stage in range(self.stages - 1, 0, -1):
+            # stage projection matrices (reference models/net.py:225-231)
+            intrinsics_l = intrinsics.clone()
+            intrinsics_l[:, :, :2] *= scale
+            proj = extrinsics.clone()
+            proj[:, :, :3, :4] = torch.matmul(intrinsics_l, extrinsics[:, :, :3, :4])
+            proj_l = torch.unbind(proj, 1)
+            ref_proj, src_proj = proj_l[0], proj_l[1:]
+            scale *= 2.0
+
+            dbg = [] if debug is not None else None
+            pm: PatchMatch = getattr(self, f"patchmatch_{stage}")
+            depths, score, view_weights = pm(
+                ref_feature=ref_feature[stage], src_features=[f[stage] for f in src_features], ref_proj=ref_proj,
+                src_projs=list(src_proj), depth_min=depth_min, depth_max=depth_max, depth=depth,
+                view_weights=view_weights, depth_shift=depth_shift, vw_shift=vw_shift,
+                noise=noise if stage == self.stages - 1 else None, debug=dbg)
+            if debug is not None:
+                debug[stage] = dbg
+            depth_patchmatch[stage] = depths
+            depth = depths[-1].detach()
+            if stage > 1:
+                # the nearest x2 up-sampling of depth and view weights (reference :272-275) is folded into the
+                # consumers: the next stage reads both maps through a coordinate shift
+                depth_shift = 1
+                vw_shift = vw_shift + 1 if view_weights.shape[-1] != depths[-1].shape[-1] else 1
+
+        depth = self.upsample_net(ref_image, depth, depth_min, depth_max)
+        if ref_width != orig_width or ref_height != orig_height:
+            depth = F.interpolate(depth, size=[orig_height, orig_width], mode="bilinear", align_corners=False)
+        depth_patchmatch[0] = [depth]
+
+        confidence, _ = ops.confidence(score.contiguous(), orig_height, orig_width)
+        return depth, confidence, depth_patchmatch
+
+
+def adjust_image_dims(images: List[torch.Tensor], intrinsics: torch.Tensor
+                      ) -> Tuple[List[torch.Tensor], torch.Tensor, int, int]:
+    """Resize every image to multiples of 8 and rescale its intrinsics IN PLACE, as reference models/net.py:304-318
+    does (callers that reuse ``intrinsics`` / the ``images`` list observe the same mutation)."""
+    _, _, ref_height, ref_width = images[0].size()
+    for i in range(len(images)):
+        _, _, height, width = images[i].size()
+        new_height = int(round(height / 8)) * 8
+        new_width = int(round(width / 8)) * 8
+        if new_width != width or new_height != height:
+            intrinsics[:, i, 0] *= new_width / width
+            intrinsics[:, i, 1] *= new_height / height
+            images[i] = F.interpolate(images[i], size=[new_height, new_width], mode="bilinear", align_corners=False)
+    return images, intrinsics, ref_height, ref_width

@@ -1,0 +1,268 @@
+"""Tensor-level entry points of the HIP path: thin, checked wrappers over the C ABI (include/pmn_hip.h).
+
+PyTorch is used here only as the owner of device memory and of the current HIP stream.  Every function requires
+float32, contiguous tensors on a ROCm device and raises otherwise -- there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PmnError, check
+
+
+# ---- optional per-launch timing of the hot kernel (bench.py's roofline leg) --------------------------------------
+# When enabled, every pmn_warp_correlate launch is bracketed by HIP events recorded on the launch stream (torch's
+# current stream) and tagged with its ALGORITHMIC byte count B_alg = 4*h*w*[(1+N)*C + D + N + G*D].
+_TIMING = None
+
+
+def enable_kernel_timing() -> None:
+    global _TIMING
+    _TIMING = []
+
+
+def disable_kernel_timing():
+    """Stops recording and returns [(milliseconds, algorithmic_bytes, tag), ...] (synchronises once)."""
+    global _TIMING
+    rec, _TIMING = _TIMING, None
+    if not rec:
+        return []
+    torch.cuda.synchronize()
+    return [(s.elapsed_time(e), nbytes, tag) for s, e, nbytes, tag in rec]
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise PmnError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise PmnError(f"{name}: tensor is on {t.device}; patchmatchnet_amd runs only on a ROCm GPU (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise PmnError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise PmnError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _host_f32(a: np.ndarray, n: int, name: str):
+    a = np.ascontiguousarray(a, np.float32)
+    if a.size != n:
+        raise PmnError(f"{name}: expected {n} floats, got {a.size}")
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _host_i32(a: np.ndarray, n: int, name: str):
+    a = np.ascontiguousarray(a, np.int32)
+    if a.size != n:
+        raise PmnError(f"{name}: expected {n} ints, got {a.size}")
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def nchw_to_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B,C,h,w] -> [B,h,w,C] (fresh tensor, or into ``out`` which may be a slice of a stacked buffer)."""
+    _dev(x, "x")
+    B, C, h, w = x.shape
+    if out is None:
+        out = torch.empty((B, h, w, C), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, "out")
+        if tuple(out.shape) != (B, h, w, C):
+            raise PmnError("nchw_to_nhwc: bad output shape")
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), B, C, h, w, _stream(x)), "pmn_nchw_to_nhwc")
+    return out
+
+
+def stack_sources_nhwc(src_features: Sequence[torch.Tensor]) -> torch.Tensor:
+    """List of N source feature maps [B,C,hs,ws] -> one channels-last buffer [N,B,hs,ws,C]."""
+    if len(src_features) == 0:
+        raise PmnError("at least one source view is required")
+    B, C, hs, ws = src_features[0].shape
+    buf = torch.empty((len(src_features), B, hs, ws, C), dtype=torch.float32, device=src_features[0].device)
+    for i, f in enumerate(src_features):
+        if tuple(f.shape) != (B, C, hs, ws):
+            raise PmnError("all source feature maps of one stage must share a shape")
+        nchw_to_nhwc(f, buf[i])
+    return buf
+
+
+def feature_weight(ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray, mlp: np.ndarray,
+                   G: int) -> torch.Tensor:
+    """FeatureWeightNet (reference models/patchmatch.py:603-624) -> [B,K,h,w]."""
+    _dev(ref_nhwc, "ref_nhwc")
+    _dev(eval_offsets, "eval_offsets")
+    B, h, w, C = ref_nhwc.shape
+    K = eval_offsets.shape[1] // 2
+    if tuple(eval_offsets.shape) != (B, 2 * K, h, w):
+        raise PmnError("feature_weight: eval_offsets must be [B,2K,h,w]")
+    tab, tab_p = _host_i32(table, 2 * K, "table")
+    blk, blk_p = _host_f32(mlp, _lib.MLP_FLOATS, "mlp")
+    out = torch.empty((B, K, h, w), dtype=torch.float32, device=ref_nhwc.device)
+    with torch.cuda.device(ref_nhwc.device):
+        check(_lib.lib().pmn_feature_weight(ref_nhwc.data_ptr(), eval_offsets.data_ptr(), tab_p, blk_p, B, C, G, K, h, w,
+                                            out.data_ptr(), _stream(out)), "pmn_feature_weight")
+    return out
+
+
+def init_hypotheses(noise: Optional[torch.Tensor], depth: Optional[torch.Tensor], depth_shift: int,
+                    depth_min: torch.Tensor, depth_max: torch.Tensor, num_sample: int, interval_scale: float,
+                    propa_offsets: Optional[torch.Tensor], table: Optional[np.ndarray], h: int, w: int
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """DepthInitialization + Propagation (reference models/patchmatch.py:53-94, 115-124).
+
+    Returns (depth_sample [B,D,h,w], xnorm [B,D,h,w])."""
+    _dev(depth_min, "depth_min")
+    _dev(depth_max, "depth_max")
+    B = depth_min.shape[0]
+    dev = depth_min.device
+    if noise is not None:
+        _dev(noise, "noise")
+        if tuple(noise.shape) != (B, 48, h, w):
+            raise PmnError("init_hypotheses: noise must be [B,48,h,w]")
+        D0 = 48
+    else:
+        if depth is None:
+            raise PmnError("init_hypotheses: need noise or depth")
+        _dev(depth, "depth")
+        if tuple(depth.shape) != (B, 1, h >> depth_shift, w >> depth_shift):
+            raise PmnError(f"init_hypotheses: depth must be [B,1,{h >> depth_shift},{w >> depth_shift}], "
+                           f"got {tuple(depth.shape)}")
+        D0 = num_sample
+    K = 0
+    tab_p = None
+    tab = None
+    if propa_offsets is not None:
+        _dev(propa_offsets, "propa_offsets")
+        K = propa_offsets.shape[1] // 2
+        if tuple(propa_offsets.shape) != (B, 2 * K, h, w):
+            raise PmnError("init_hypotheses: propa_offsets must be [B,2K,h,w]")
+        tab, tab_p = _host_i32(table, 2 * K, "table")
+    D = D0 + K
+    ds = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    xn = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().pmn_init_hypotheses(_ptr(noise), _ptr(depth) if noise is None else None, depth_shift,
+                                             depth_min.data_ptr(), depth_max.data_ptr(), num_sample,
+                                             float(interval_scale), _ptr(propa_offsets), tab_p, K, B, h, w,
+                                             ds.data_ptr(), xn.data_ptr(), _stream(ds)), "pmn_init_hypotheses")
+    del tab
+    return ds, xn
+
+
+def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: torch.Tensor, depth_sample: torch.Tensor,
+                   view_weights: Optional[torch.Tensor], vw_shift: int, similarity_mlp: np.ndarray,
+                   pixelwise_mlp: Optional[np.ndarray], G: int, want_similarity: bool = False,
+                   want_argmax: bool = False):
+    """The fused warp + gather + group-correlation + view aggregation + SimilarityNet-MLP kernel.
+
+    Returns (cost [B,D,h,w], view_weights [B,N,h,w] (input passed through, or computed), argmax or None,
+    aggregated similarity [B,G,D,h,w] or None)."""
+    _dev(ref_nhwc, "ref_nhwc")
+    _dev(src_nhwc, "src_nhwc")
+    _dev(rel_proj, "rel_proj")
+    _dev(depth_sample, "depth_sample")
+    B, h, w, C = ref_nhwc.shape
+    N, Bs, hs, ws, Cs = src_nhwc.shape
+    D = depth_sample.shape[1]
+    if Bs != B or Cs != C or tuple(depth_sample.shape) != (B, D, h, w) or tuple(rel_proj.shape) != (B, N, 4, 4):
+        raise PmnError("warp_correlate: inconsistent shapes")
+    dev = ref_nhwc.device
+    sim_blk, sim_p = _host_f32(similarity_mlp, _lib.MLP_FLOATS, "similarity_mlp")
+    pix_blk, pix_p, vw_out, argmax = None, None, None, None
+    if view_weights is not None:
+        _dev(view_weights, "view_weights")
+        if tuple(view_weights.shape) != (B, N, h >> vw_shift, w >> vw_shift):
+            raise PmnError("Patchmatch Evaluation: Different number of images and view weights")
+    else:
+        if pixelwise_mlp is None:
+            raise PmnError("warp_correlate: pixelwise_mlp required when view_weights is None")
+        pix_blk, pix_p = _host_f32(pixelwise_mlp, _lib.MLP_FLOATS, "pixelwise_mlp")
+        vw_out = torch.empty((B, N, h, w), dtype=torch.float32, device=dev)
+        if want_argmax:
+            argmax = torch.empty((B, N, h, w), dtype=torch.int32, device=dev)
+    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    sim = torch.empty((B, G, D, h, w), dtype=torch.float32, device=dev) if want_similarity else None
+    with torch.cuda.device(dev):
+        if _TIMING is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        check(_lib.lib().pmn_warp_correlate(ref_nhwc.data_ptr(), src_nhwc.data_ptr(), rel_proj.data_ptr(),
+                                            depth_sample.data_ptr(), _ptr(view_weights), vw_shift, sim_p, pix_p, B, N, C,
+                                            G, D, h, w, hs, ws, cost.data_ptr(), _ptr(vw_out), _ptr(argmax), _ptr(sim),
+                                            _stream(cost)), "pmn_warp_correlate")
+        if _TIMING is not None:
+            ev1.record()
+            _TIMING.append((ev0, ev1, 4 * B * h * w * ((1 + N) * C + D + N + G * D),
+                            f"C{C}_D{D}_{h}x{w}_N{N}_{'vw' if view_weights is not None else 'pixelwise'}"))
+    return cost, (view_weights if view_weights is not None else vw_out), argmax, sim
+
+
+def aggregate_regress(cost: torch.Tensor, depth_sample: torch.Tensor, xnorm: torch.Tensor, feature_weight_: torch.Tensor,
+                      eval_offsets: torch.Tensor, table: np.ndarray, interval_scale: float, is_inverse: bool
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Adaptive spatial aggregation + softmax + regression -> (score [B,D,h,w], depth [B,h,w])."""
+    for n, t in (("cost", cost), ("depth_sample", depth_sample), ("xnorm", xnorm), ("feature_weight", feature_weight_),
+                 ("eval_offsets", eval_offsets)):
+        _dev(t, n)
+    B, D, h, w = cost.shape
+    K = feature_weight_.shape[1]
+    if tuple(depth_sample.shape) != (B, D, h, w) or tuple(xnorm.shape) != (B, D, h, w) or \
+            tuple(feature_weight_.shape) != (B, K, h, w) or tuple(eval_offsets.shape) != (B, 2 * K, h, w):
+        raise PmnError("aggregate_regress: inconsistent shapes")
+    tab, tab_p = _host_i32(table, 2 * K, "table")
+    score = torch.empty((B, D, h, w), dtype=torch.float32, device=cost.device)
+    depth = torch.empty((B, h, w), dtype=torch.float32, device=cost.device)
+    with torch.cuda.device(cost.device):
+        check(_lib.lib().pmn_aggregate_regress(cost.data_ptr(), depth_sample.data_ptr(), xnorm.data_ptr(),
+                                               feature_weight_.data_ptr(), eval_offsets.data_ptr(), tab_p, K,
+                                               float(interval_scale), 1 if is_inverse else 0, B, D, h, w,
+                                               score.data_ptr(), depth.data_ptr(), _stream(cost)),
+              "pmn_aggregate_regress")
+    return score, depth
+
+
+def confidence(score: torch.Tensor, H: int, W: int, want_index: bool = False):
+    """Photometric confidence (reference models/net.py:288-299) -> ([B,H,W], depth_index [B,h,w] int32 or None)."""
+    _dev(score, "score")
+    B, D, h, w = score.shape
+    conf = torch.empty((B, H, W), dtype=torch.float32, device=score.device)
+    idx = torch.empty((B, h, w), dtype=torch.int32, device=score.device) if want_index else None
+    with torch.cuda.device(score.device):
+        check(_lib.lib().pmn_confidence(score.data_ptr(), B, D, h, w, H, W, conf.data_ptr(), _ptr(idx), _stream(score)),
+              "pmn_confidence")
+    return conf, idx
+
+
+def relative_projection(src_projs: Sequence[torch.Tensor], ref_proj: torch.Tensor) -> torch.Tensor:
+    """src_proj @ inverse(ref_proj) for every source view (reference models/module.py:148) -> [B,N,4,4]."""
+    inv = torch.inverse(ref_proj)
+    return torch.matmul(torch.stack(list(src_projs), dim=1), inv.unsqueeze(1)).contiguous()
+
+
+def differentiable_warping(src_fea: torch.Tensor, src_proj: torch.Tensor, ref_proj: torch.Tensor,
+                           depth_samples: torch.Tensor) -> torch.Tensor:
+    """Drop-in for reference models/module.py:130-181 (inference): [B,C,Hs,Ws],[B,4,4],[B,4,4],[B,D,H,W] -> [B,C,D,H,W]."""
+    src_fea = _dev(src_fea.contiguous(), "src_fea")
+    depth_samples = _dev(depth_samples.contiguous(), "depth_samples")
+    B, C, hs, ws = src_fea.shape
+    _, D, h, w = depth_samples.shape
+    proj = torch.matmul(src_proj, torch.inverse(ref_proj)).contiguous()
+    _dev(proj, "proj")
+    out = torch.empty((B, C, D, h, w), dtype=torch.float32, device=src_fea.device)
+    with torch.cuda.device(src_fea.device):
+        check(_lib.lib().pmn_differentiable_warping(src_fea.data_ptr(), proj.data_ptr(), depth_samples.data_ptr(), B, C,
+                                                    D, h, w, hs, ws, out.data_ptr(), _stream(out)),
+              "pmn_differentiable_warping")
+    return out

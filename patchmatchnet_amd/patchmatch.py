@@ -1,0 +1,242 @@
+"""Learned PatchMatch on MI355X: host-side mirror of the reference's ``models/patchmatch.py`` interface.
+
+``PatchMatch.forward`` keeps the reference signature and return values (models/patchmatch.py:428-529) and the module
+tree keeps the reference's parameter names, so ``params_000007.ckpt`` loads unchanged.  The arithmetic runs in four
+HIP kernels per iteration-independent / per-iteration step (see patchmatchnet_amd/csrc):
+
+    once per stage   propa_conv / eval_conv (MIOpen 3x3 dilated convs, kept on PyTorch-ROCm per the north star)
+                     pmn_nchw_to_nhwc       feature maps -> channels-last
+                     pmn_feature_weight     FeatureWeightNet (+ get_grid)
+    per iteration    pmn_init_hypotheses    DepthInitialization + Propagation (+ per-pixel sort)
+                     pmn_warp_correlate     differentiable_warping + group correlation + PixelwiseNet / view
+                                            aggregation + SimilarityNet MLP               <- the hot kernel
+                     pmn_aggregate_regress  depth_weight + adaptive aggregation + softmax + regression
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, params
+from ._lib import PmnError
+from .module import ConvBnReLU3D, is_empty
+
+
+class _PointwiseMLP(nn.Module):
+    """G -> 16 -> 8 -> 1 pointwise network; ``_last`` names the final Conv3d attribute."""
+
+    _last = "similarity"
+
+    def __init__(self, G: int) -> None:
+        super().__init__()
+        self.G = G
+        self.conv0 = ConvBnReLU3D(in_channels=G, out_channels=16, kernel_size=1, stride=1, pad=0)
+        self.conv1 = ConvBnReLU3D(in_channels=16, out_channels=8, kernel_size=1, stride=1, pad=0)
+        self._packed: Optional[np.ndarray] = None
+        self._packed_key = None
+
+    def _sources(self) -> List[torch.Tensor]:
+        last = getattr(self, self._last)
+        return [self.conv0.conv.weight, *self.conv0.bn_tensors(), self.conv1.conv.weight, *self.conv1.bn_tensors(),
+                last.weight, last.bias]
+
+    def packed(self) -> np.ndarray:
+        """BN-folded float32[289] block for the kernel-argument segment (cached until a parameter changes)."""
+        key = params.versions(self._sources())
+        if self._packed is None or key != self._packed_key:
+            last = getattr(self, self._last)
+            self._packed = params.pack_mlp(self.conv0.conv.weight, self.conv0.bn_tensors(), self.conv1.conv.weight,
+                                           self.conv1.bn_tensors(), last.weight, last.bias)
+            self._packed_key = key
+        return self._packed
+
+
+class PixelwiseNet(_PointwiseMLP):
+    """Pixel-wise view weight network (reference models/patchmatch.py:672-702); evaluated inside pmn_warp_correlate."""
+
+    _last = "conv2"
+
+    def __init__(self, G: int) -> None:
+        super().__init__(G)
+        self.conv2 = nn.Conv3d(in_channels=8, out_channels=1, kernel_size=1, stride=1, padding=0)
+        self.output = nn.Sigmoid()
+
+
+class SimilarityNet(_PointwiseMLP):
+    """Similarity network (reference models/patchmatch.py:532-577): MLP inside pmn_warp_correlate, neighbour
+    aggregation inside pmn_aggregate_regress."""
+
+    def __init__(self, G: int) -> None:
+        super().__init__(G)
+        self.similarity = nn.Conv3d(in_channels=8, out_channels=1, kernel_size=1, stride=1, padding=0)
+
+
+class FeatureWeightNet(_PointwiseMLP):
+    """Feature weight network (reference models/patchmatch.py:580-624) -> pmn_feature_weight."""
+
+    def __init__(self, neighbors: int = 9, G: int = 8) -> None:
+        super().__init__(G)
+        self.neighbors = neighbors
+        self.similarity = nn.Conv3d(in_channels=8, out_channels=1, kernel_size=1, stride=1, padding=0)
+        self.output = nn.Sigmoid()
+
+    def forward(self, ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray) -> torch.Tensor:
+        """ref_nhwc [B,h,w,C], eval_offsets [B,2K,h,w] (raw eval_conv output) -> weights [B,K,h,w]."""
+        return ops.feature_weight(ref_nhwc, eval_offsets, table, self.packed(), self.G)
+
+
+class DepthInitialization(nn.Module):
+    """Hypothesis generation (reference models/patchmatch.py:17-94), fused with Propagation in pmn_init_hypotheses."""
+
+    def __init__(self, patchmatch_num_sample: int = 1) -> None:
+        super().__init__()
+        self.patchmatch_num_sample = patchmatch_num_sample
+
+    def forward(self, min_depth: torch.Tensor, max_depth: torch.Tensor, height: int, width: int,
+                depth_interval_scale: float, device: torch.device, depth: torch.Tensor) -> torch.Tensor:
+        """Same signature as the reference; returns depth_sample [B,D,H,W] (no propagation)."""
+        noise = None
+        if is_empty(depth):
+            noise = torch.rand(size=(min_depth.size()[0], 48, height, width), device=device)
+        ds, _ = ops.init_hypotheses(noise, None if noise is not None else depth.detach().contiguous(), 0,
+                                    min_depth.float().contiguous(), max_depth.float().contiguous(),
+                                    self.patchmatch_num_sample, depth_interval_scale, None, None, height, width)
+        return ds
+
+
+class Propagation(nn.Module):
+    """Adaptive propagation (reference models/patchmatch.py:97-124); executed inside pmn_init_hypotheses."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+
+class Evaluation(nn.Module):
+    """Adaptive evaluation (reference models/patchmatch.py:127-239): pmn_warp_correlate + pmn_aggregate_regress."""
+
+    def __init__(self, G: int = 8) -> None:
+        super().__init__()
+        self.G = G
+        self.pixel_wise_net = PixelwiseNet(self.G)
+        self.softmax = nn.LogSoftmax(dim=1)
+        self.similarity_net = SimilarityNet(self.G)
+
+    def forward(self, ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: torch.Tensor,
+                depth_sample: torch.Tensor, xnorm: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray,
+                feature_weight: torch.Tensor, view_weights: torch.Tensor, vw_shift: int, interval_scale: float,
+                is_inverse: bool, debug: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Fused-form arguments (channels-last features, relative projections, raw offsets instead of grid/weight).
+
+        Returns (depth [B,h,w], score [B,D,h,w], view_weights [B,N,h,w]) like the reference."""
+        N = src_nhwc.shape[0]
+        have_vw = not is_empty(view_weights)
+        if have_vw and view_weights.size()[1] != N:
+            raise AssertionError("Patchmatch Evaluation: Different number of images and view weights")
+        cost, vw, argmax, sim = ops.warp_correlate(
+            ref_nhwc, src_nhwc, rel_proj, depth_sample, view_weights if have_vw else None, vw_shift,
+            self.similarity_net.packed(), None if have_vw else self.pixel_wise_net.packed(), self.G,
+            want_similarity=debug is not None, want_argmax=debug is not None and not have_vw)
+        score, depth = ops.aggregate_regress(cost, depth_sample, xnorm, feature_weight, eval_offsets, table,
+                                             interval_scale, is_inverse)
+        if debug is not None:
+            debug.update(cost=cost, similarity=sim, view_weight_argmax=argmax)
+        return depth, score, vw.detach()
+
+
+class PatchMatch(nn.Module):
+    """One PatchMatch stage; constructor and ``forward`` as the reference (models/patchmatch.py:242-312, 428-529)."""
+
+    def __init__(self, propagation_out_range: int = 2, patchmatch_iteration: int = 2, patchmatch_num_sample: int = 16,
+                 patchmatch_interval_scale: float = 0.025, num_feature: int = 64, G: int = 8,
+                 propagate_neighbors: int = 16, evaluate_neighbors: int = 9, stage: int = 3) -> None:
+        super().__init__()
+        self.patchmatch_iteration = patchmatch_iteration
+        self.patchmatch_interval_scale = patchmatch_interval_scale
+        self.propa_num_feature = num_feature
+        self.G = G
+        self.stage = stage
+        self.dilation = propagation_out_range
+        self.propagate_neighbors = propagate_neighbors
+        self.evaluate_neighbors = evaluate_neighbors
+        if propagate_neighbors not in (0, 4, 8, 16) or evaluate_neighbors not in (9, 17):
+            raise NotImplementedError  # same legal sets as reference get_grid (:331-394)
+
+        self.depth_initialization = DepthInitialization(patchmatch_num_sample)
+        self.propagation = Propagation()
+        self.evaluation = Evaluation(self.G)
+        # offset heads stay on MIOpen; zero-initialised like the reference (:288-311)
+        self.propa_conv = nn.Conv2d(num_feature, max(2 * propagate_neighbors, 1), kernel_size=3, stride=1,
+                                    padding=self.dilation, dilation=self.dilation, bias=True)
+        nn.init.constant_(self.propa_conv.weight, 0.0)
+        nn.init.constant_(self.propa_conv.bias, 0.0)
+        self.eval_conv = nn.Conv2d(num_feature, 2 * evaluate_neighbors, kernel_size=3, stride=1, padding=self.dilation,
+                                   dilation=self.dilation, bias=True)
+        nn.init.constant_(self.eval_conv.weight, 0.0)
+        nn.init.constant_(self.eval_conv.bias, 0.0)
+        self.feature_weight_net = FeatureWeightNet(evaluate_neighbors, self.G)
+
+        self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
+        self._etable = params.evaluation_table(evaluate_neighbors, self.dilation)
+
+    def forward(self, ref_feature: torch.Tensor, src_features: List[torch.Tensor], ref_proj: torch.Tensor,
+                src_projs: List[torch.Tensor], depth_min: torch.Tensor, depth_max: torch.Tensor, depth: torch.Tensor,
+                view_weights: torch.Tensor, depth_shift: int = 0, vw_shift: int = 0, noise: Optional[torch.Tensor] = None,
+                debug: Optional[list] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+        """Reference arguments, plus optional extras that default to reference behaviour:
+        ``depth_shift`` / ``vw_shift`` = 1 read ``depth`` / ``view_weights`` given at half resolution through the
+        nearest x2 up-sampling (skips materialising F.interpolate); ``noise`` pins the stage-3 random draw;
+        ``debug`` (a list) receives one dict of intermediates per iteration."""
+        if len(src_features) != len(src_projs):
+            raise AssertionError("Patchmatch Evaluation: Different number of images and projection matrices")
+        if not ref_feature.is_cuda:
+            raise PmnError("patchmatchnet_amd.PatchMatch runs on a ROCm GPU only (no CPU fallback)")
+        device = ref_feature.device
+        batch, _, height, width = ref_feature.size()
+        ref_feature = ref_feature.contiguous()
+
+        propagate_any = self.propagate_neighbors > 0 and not (self.stage == 1 and self.patchmatch_iteration == 1)
+        propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None
+        eval_offsets = self.eval_conv(ref_feature).contiguous()
+
+        ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
+        src_nhwc = ops.stack_sources_nhwc([f.detach().contiguous() for f in src_features])
+        rel_proj = ops.relative_projection(src_projs, ref_proj)
+        depth_min = depth_min.float().contiguous()
+        depth_max = depth_max.float().contiguous()
+
+        feature_weight = self.feature_weight_net(ref_nhwc, eval_offsets, self._etable)
+
+        depth_sample = depth
+        cur_shift = depth_shift
+        score = torch.empty(0, device=device)
+        depth_samples: List[torch.Tensor] = []
+        for it in range(1, self.patchmatch_iteration + 1):
+            is_inverse = self.stage == 1 and it == self.patchmatch_iteration
+            first_random = is_empty(depth_sample)
+            if first_random and noise is None:
+                # same RNG call as the reference (models/patchmatch.py:61-62) so a seeded run draws the same numbers
+                noise = torch.rand(size=(batch, 48, height, width), device=device)
+            propagate = self.propagate_neighbors > 0 and not (self.stage == 1 and it == self.patchmatch_iteration)
+            hyp, xnorm = ops.init_hypotheses(
+                noise.contiguous() if first_random else None,
+                None if first_random else depth_sample.detach().contiguous(), cur_shift, depth_min, depth_max,
+                self.depth_initialization.patchmatch_num_sample, self.patchmatch_interval_scale,
+                propa_offsets if propagate else None, self._ptable if propagate else None, height, width)
+            rec = {} if debug is not None else None
+            had_view_weights = not is_empty(view_weights)
+            d, score, view_weights = self.evaluation(
+                ref_nhwc, src_nhwc, rel_proj, hyp, xnorm, eval_offsets, self._etable, feature_weight, view_weights,
+                vw_shift, self.patchmatch_interval_scale, is_inverse, debug=rec)
+            if not had_view_weights:
+                vw_shift = 0  # weights were just computed at this stage's resolution
+            if rec is not None:
+                rec.update(depth_sample=hyp, xnorm=xnorm, feature_weight=feature_weight, score=score, depth=d,
+                           view_weights=view_weights, eval_offsets=eval_offsets, propa_offsets=propa_offsets)
+                debug.append(rec)
+            depth_sample = d.unsqueeze(1)
+            cur_shift = 0
+            depth_samples.append(depth_sample)
+        return depth_samples, score, view_weights

@@ -5,7 +5,6 @@ Only usable in the authoring container: the GPU box has no ``/root/reference``. 
 """
 from __future__ import annotations
 
-import math
 import os
 import sys
 from contextlib import contextmanager
@@ -49,36 +48,7 @@ def build_reference_model(**overrides):
     return model.eval()
 
 
-def synthetic_cameras(n_views: int, H: int, W: int):
-    """DTU-like pinhole cameras orbiting the point (0,0,650)."""
-    f = 2892.33 * W / 1600.0
-    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float64)
-    intr = np.stack([K] * n_views).astype(np.float32)
-    extr = []
-    P = np.array([0.0, 0.0, 650.0])
-    for i in range(n_views):
-        a = 0.0 if i == 0 else 0.08 * i * (1.0 if i % 2 else -1.0)
-        R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
-        E = np.eye(4)
-        E[:3, :3] = R
-        E[:3, 3] = P - R @ P
-        extr.append(E)
-    return intr[None], np.stack(extr).astype(np.float32)[None]
-
-
-def synthetic_images(n_views: int, H: int, W: int, smooth: bool = True) -> List[torch.Tensor]:
-    """Seeded images.  ``smooth`` low-pass filters the noise so views look alike enough for a peaked cost."""
-    imgs = []
-    for i in range(n_views):
-        g = torch.Generator().manual_seed(i if not smooth else 0)
-        img = torch.rand(1, 3, H, W, generator=g)
-        if smooth:
-            k = 9
-            img = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(img, (k // 2,) * 4, mode="reflect"), k, 1)
-            img = torch.roll(img, shifts=3 * i, dims=3)
-            img = (img - img.min()) / (img.max() - img.min())
-        imgs.append(img.contiguous())
-    return imgs
+from synth import synthetic_cameras, synthetic_images  # noqa: E402,F401  (shared seeded generators)
 
 
 @contextmanager

@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports exactly the entry
+points include/pmn_hip.h declares (no compute calls -- there is no GPU in the authoring container)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pmn_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decl = {}
+    for m in re.finditer(r"\b(?:int|const char \*)\s*(pmn_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",")]
+        decl[m.group(1)] = 0 if args == ["void"] else len(args)
+    return decl
+
+
+def test_header_declares_the_signature_table():
+    from patchmatchnet_amd import _lib
+    decl = _declared()
+    assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
+    for name, nargs in decl.items():
+        assert nargs == len(_lib.SIGNATURES[name]), name
+    hdr = open(HEADER).read()
+    assert f"#define PMN_MLP_FLOATS {_lib.MLP_FLOATS}" in hdr
+    assert f"#define PMN_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+
+
+def test_library_builds_loads_and_exports_every_symbol():
+    from patchmatchnet_amd import _lib
+    _lib.build()
+    L = _lib.lib()
+    assert L.pmn_abi_version() == _lib.ABI_VERSION
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    for name in _declared():
+        assert name in exported, name
+    assert L.pmn_error_string(-2).decode().startswith("unsupported shape")
+    # the code object really targets gfx950
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_argument_checks_do_not_launch():
+    """Bad arguments are rejected on the host before any HIP call (safe without a GPU)."""
+    from patchmatchnet_amd import _lib
+    L = _lib.lib()
+    assert L.pmn_nchw_to_nhwc(None, None, 1, 4, 4, 4, None) == -1
+    assert L.pmn_confidence(None, 1, 8, 4, 4, 8, 8, None, None, None) == -1
+    assert L.pmn_warp_correlate(None, None, None, None, None, 0, None, None, 1, 1, 64, 8, 8, 4, 4, 4, 4, None, None,
+                                None, None, None) == -1
+
+
+def test_product_refuses_cpu_tensors_and_training_mode():
+    import patchmatchnet_amd as P
+    with pytest.raises(P.PmnError):
+        P.ops.nchw_to_nhwc(torch.zeros(1, 4, 4, 4))
+    kw = dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+              patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[8, 8, 16], propagate_neighbors=[0, 8, 16],
+              evaluate_neighbors=[9, 9, 9])
+    m = P.PatchmatchNet(**kw)
+    with pytest.raises(P.PmnError):  # training mode: inference-only engine
+        m([torch.zeros(1, 3, 64, 64)] * 2, torch.eye(3).repeat(1, 2, 1, 1), torch.eye(4).repeat(1, 2, 1, 1),
+          torch.ones(1), 2 * torch.ones(1))
+    with pytest.raises(NotImplementedError):  # same legal neighbour counts as the reference get_grid
+        P.PatchMatch(propagate_neighbors=5)
+
+
+def test_state_dict_names_match_reference_checkpoint():
+    import goldenutil as GU
+    import patchmatchnet_amd as P
+    _, params, kw = GU.load_case("default")
+    m = P.PatchmatchNet(**kw)
+    own = m.state_dict()
+    assert set(own) == set(params)
+    for k, v in params.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    # DataParallel-style prefixes are accepted (reference eval.py:33-35)
+    m.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+
+
+def test_mlp_packing_folds_batchnorm():
+    import goldenutil as GU
+    import patchmatchnet_amd as P
+    from oracle import oracle as O
+    _, params, kw = GU.load_case("default")
+    m = P.PatchmatchNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    net = m.patchmatch_1.evaluation.similarity_net
+    blk = net.packed().astype(np.float64)
+    G = 4
+    x = np.random.default_rng(0).standard_normal((1, G, 50)).astype(np.float32)
+    ref = O.pointwise_mlp(x, params, "patchmatch_1.evaluation.similarity_net", "similarity", sigmoid=False)[0]
+    w0, t0 = blk[:16 * G].reshape(16, G), blk[128:144]
+    w1, t1, w2, b2 = blk[144:272].reshape(8, 16), blk[272:280], blk[280:288], blk[288]
+    h0 = np.maximum(w0 @ x[0].astype(np.float64) + t0[:, None], 0)
+    h1 = np.maximum(w1 @ h0 + t1[:, None], 0)
+    out = w2 @ h1 + b2
+    assert (np.abs(out - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-4
+    assert net.packed() is net.packed()  # cached

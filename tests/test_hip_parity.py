@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference-generated golden vectors.
+
+Run with ``pytest -m gpu`` on an MI355X.  Tolerances: north_star asks <= 1e-3 relative on depth and exact view-weight
+indices; kernel-level comparisons (same inputs on both sides) are held much tighter than that.
+"""
+import numpy as np
+import pytest
+import torch
+
+import goldenutil as GU
+import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _gpu():
+    # fail loudly (never skip) when selected with -m gpu on a box without a usable GPU / library
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    import patchmatchnet_amd as P
+    P.lib()
+    return P
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def _model(P, params, kw):
+    m = P.PatchmatchNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+def _configs(kw):
+    return O.default_stage_configs(kw["patchmatch_interval_scale"], kw["propagation_range"],
+                                   kw["patchmatch_iteration"], kw["patchmatch_num_sample"],
+                                   kw["propagate_neighbors"], kw["evaluate_neighbors"])
+
+
+def test_library_is_the_compute_path():
+    P = _gpu()
+    assert P.lib().pmn_abi_version() == 1
+    with pytest.raises(P.PmnError):  # CPU tensors are refused, there is no fallback
+        P.ops.nchw_to_nhwc(torch.zeros(1, 4, 4, 4))
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_differentiable_warping_op(name):
+    P = _gpu()
+    g = GU.load_npz("ops_small.npz")
+    out = P.differentiable_warping(t(g[f"{name}_src"]), t(g[f"{name}_src_proj"]), t(g[f"{name}_ref_proj"]),
+                                   t(g[f"{name}_depth"]))
+    ref = g[f"{name}_warped"]
+    assert GU.abs_err(n(out), ref) < 5e-5
+    oracle = O.differentiable_warping(g[f"{name}_src"], g[f"{name}_src_proj"], g[f"{name}_ref_proj"], g[f"{name}_depth"])
+    frac_zero_mismatch = float(((n(out) == 0) != (oracle == 0)).mean())
+    assert frac_zero_mismatch < 1e-3  # the inverse may differ in the last bit between LAPACK and the GPU solver
+
+
+def test_nchw_to_nhwc_roundtrip():
+    P = _gpu()
+    x = torch.randn(2, 32, 37, 53, device=DEV)
+    y = P.ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+
+
+@pytest.mark.parametrize("case", ["default", "variant"])
+@pytest.mark.parametrize("stage", [3, 2, 1])
+def test_kernels_against_golden(case, stage):
+    """Every kernel of one stage, fed the reference's own tensors (incl. its conv offsets), against the reference's
+    intermediates (golden) and against the oracle's arg-max indices."""
+    P = _gpu()
+    g, params, kw = GU.load_case(case)
+    cfg = _configs(kw)[stage]
+    feats, proj, depth, vw = GU.stage_inputs(g, kw, stage)
+    model = _model(P, params, kw)
+    pm = getattr(model, f"patchmatch_{stage}")
+    B, C, h, w = feats[0].shape
+
+    ref_nhwc = P.ops.nchw_to_nhwc(t(feats[0]))
+    src_nhwc = P.ops.stack_sources_nhwc([t(f) for f in feats[1:]])
+    # relative projections computed exactly as the oracle does (numpy fp32) so both sides sample identical positions;
+    # ops.relative_projection (torch.inverse on the device) is exercised by the module-level tests below
+    rel = t(np.stack([np.matmul(proj[:, i], np.linalg.inv(proj[:, 0])) for i in range(1, proj.shape[1])], 1)
+            .astype(np.float32))
+    eval_off = t(g[f"s{stage}_eval_offsets"])
+    propa_off = t(g[f"s{stage}_propa_offsets"]) if f"s{stage}_propa_offsets" in g else None
+    dmin, dmax = t(g["depth_min"]), t(g["depth_max"])
+
+    fw = pm.feature_weight_net(ref_nhwc, eval_off, pm._etable)
+    assert GU.abs_err(n(fw), g[f"s{stage}_feature_weight"]) < 2e-5
+
+    # oracle run for the arg-max indices (not stored in the fixtures)
+    otr = []
+    O.patchmatch_stage(cfg, params, feats[0], feats[1:], proj[:, 0], [proj[:, i] for i in range(1, proj.shape[1])],
+                       g["depth_min"], g["depth_max"], depth, vw, noise=g["noise"] if stage == 3 else None,
+                       propa_offsets=g.get(f"s{stage}_propa_offsets"), eval_offsets=g[f"s{stage}_eval_offsets"],
+                       trace=otr)
+
+    for it in range(1, cfg.iterations + 1):
+        key = f"s{stage}_it{it}_"
+        is_inverse = stage == 1 and it == cfg.iterations
+        propagate = cfg.propagate_neighbors > 0 and not (stage == 1 and it == cfg.iterations)
+        # inputs of this iteration are the GOLDEN outputs of the previous one: kernels are compared in isolation
+        if it == 1:
+            d_in = None if depth is None else t(depth)
+        else:
+            d_in = t(g[f"s{stage}_it{it - 1}_depth_out"])
+        first = stage == 3 and it == 1
+        hyp, xn = P.ops.init_hypotheses(t(g["noise"]) if first else None, d_in, 0, dmin, dmax, cfg.num_sample,
+                                        cfg.interval_scale, propa_off if propagate else None,
+                                        pm._ptable if propagate else None, h, w)
+        assert GU.rel_err(n(hyp), g[key + "depth_sample"]) < 2e-6
+        hyp = t(g[key + "depth_sample"])  # continue from the golden hypotheses
+        inv_min, inv_max = 1.0 / g["depth_min"].reshape(-1, 1, 1, 1), 1.0 / g["depth_max"].reshape(-1, 1, 1, 1)
+        xn_ref = (1.0 / g[key + "depth_sample"] - inv_max) / (inv_min - inv_max)
+        if first:
+            vw_in = None
+        elif it == 1:
+            vw_in = t(vw)
+        else:
+            vw_in = t(g[f"s{stage}_it{it - 1}_view_weights"])
+        cost, vw_out, argmax, sim = P.ops.warp_correlate(
+            ref_nhwc, src_nhwc, rel, hyp, vw_in, 0, pm.evaluation.similarity_net.packed(),
+            pm.evaluation.pixel_wise_net.packed() if vw_in is None else None, cfg.G, want_similarity=True,
+            want_argmax=vw_in is None)
+        assert GU.abs_err(n(sim), g[key + "similarity"]) < 5e-5
+        assert GU.abs_err(n(vw_out), g[key + "view_weights"]) < 1e-5
+        if vw_in is None:
+            # "bit-exact on view_weights indices": arg-max over D of the PixelwiseNet response == oracle's
+            np.testing.assert_array_equal(n(argmax), otr[it - 1]["view_weight_argmax"])
+        assert GU.abs_err(n(cost), otr[it - 1]["cost"]) < 2e-4
+        score, dep = P.ops.aggregate_regress(t(otr[it - 1]["cost"]), hyp, t(xn_ref.astype(np.float32)), fw, eval_off,
+                                             pm._etable, cfg.interval_scale, is_inverse)
+        assert GU.abs_err(n(score), g[key + "score"]) < 2e-4
+        assert GU.rel_err(n(dep), g[key + "depth"]) < 2e-5
+
+
+@pytest.mark.parametrize("case", ["default", "variant"])
+def test_cascade_with_reference_features(case):
+    """PatchmatchNet.forward fed the reference's FeatureNet outputs and noise: whole hot path + MIOpen offset heads +
+    refinement + confidence vs the reference's final outputs (north_star tolerance 1e-3 relative on depth)."""
+    P = _gpu()
+    g, params, kw = GU.load_case(case)
+    model = _model(P, params, kw)
+    nv = int(g["n_views"])
+    feats = [{s: t(g[f"feature_{v}_s{s}"]) for s in (1, 2, 3)} for v in range(nv)]
+    imgs = [t(g[f"image_{v}"]) for v in range(nv)]
+    dbg = {}
+    with torch.no_grad():
+        depth, conf, dpm = model(imgs, t(g["intrinsics"]), t(g["extrinsics"]), t(g["depth_min"]), t(g["depth_max"]),
+                                 noise=t(g["noise"]), features=feats, debug=dbg)
+    last = kw["patchmatch_iteration"][0]
+    for stage in (3, 2, 1):
+        for it in range(1, kw["patchmatch_iteration"][stage - 1] + 1):
+            e = GU.rel_err(n(dpm[stage][it - 1]), g[f"s{stage}_it{it}_depth_out"])
+            assert e < 1e-3, (stage, it, e)
+    assert GU.rel_err(n(dpm[1][last - 1]), g[f"s1_it{last}_depth_out"]) < 1e-3
+    assert GU.rel_err(n(depth), g["depth"]) < 1e-3
+    assert depth.shape == g["depth"].shape and conf.shape == g["confidence"].shape
+    mism = float((np.abs(n(conf) - g["confidence"]) > 1e-3).mean())
+    assert mism < 5e-3, mism  # confidence hinges on trunc(sum d*p): statistical criterion
+
+
+def test_end_to_end_from_images():
+    """FeatureNet (MIOpen) + hot path + refinement from raw images vs the reference's CPU result.  FeatureNet rounding
+    differs between MIOpen and the CPU backend and amplifies down the cascade, so the criterion is statistical."""
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    nv = int(g["n_views"])
+    imgs = [t(g[f"image_{v}"]) for v in range(nv)]
+    with torch.no_grad():
+        depth, conf, _ = model(imgs, t(g["intrinsics"]), t(g["extrinsics"]), t(g["depth_min"]), t(g["depth_max"]),
+                               noise=t(g["noise"]))
+    rel = np.abs(n(depth) - g["depth"]) / np.abs(g["depth"])
+    assert np.quantile(rel, 0.999) < 1e-3, float(np.quantile(rel, 0.999))
+    assert rel.max() < 2e-2, float(rel.max())
+
+
+def test_view_weight_upsampling_shift_matches_materialised():
+    """vw_shift / depth_shift (nearest up-sampling folded into the consumer) == explicit F.interpolate."""
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    feats, proj, depth, vw = GU.stage_inputs(g, kw, 2)
+    pm = model.patchmatch_2
+    args = dict(ref_feature=t(feats[0]), src_features=[t(f) for f in feats[1:]], ref_proj=t(proj[:, 0]),
+                src_projs=[t(proj[:, i]) for i in range(1, proj.shape[1])], depth_min=t(g["depth_min"]),
+                depth_max=t(g["depth_max"]))
+    with torch.no_grad():
+        a = pm(depth=t(depth), view_weights=t(vw), **args)
+        half_d = t(g["s3_it2_depth_out"])
+        half_vw = t(g["s3_it2_view_weights"])
+        b = pm(depth=half_d, view_weights=half_vw, depth_shift=1, vw_shift=1, **args)
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[1], b[1])
+
+
+# ---- BASELINE-size checks -------------------------------------------------------------------------------------------
+
+def _fullsize_stage(P, stage, n_src, H, W, params, kw, seed=0):
+    scale = {3: 8, 2: 4, 1: 2}[stage]
+    C = {3: 64, 2: 32, 1: 16}[stage]
+    h, w = H // scale, W // scale
+    feats = synth.synthetic_features(n_src + 1, C, h, w, seed=seed)
+    intr, extr = synth.synthetic_cameras(n_src + 1, H, W)
+    proj = synth.stage_projections(intr, extr, 1.0 / scale)
+    return feats, proj, h, w
+
+
+@pytest.mark.parametrize("stage,n_src,H,W", [(3, 5, 1200, 1600), (1, 5, 1200, 1600), (2, 7, 1056, 1920)])
+def test_fullsize_stage_against_oracle(stage, n_src, H, W):
+    """One PatchMatch stage at BASELINE config sizes (cfg-2: 1600x1200 N=5; cfg-3: 1920x1056 N=7) vs the CPU oracle on
+    identical inputs (same conv offsets), plus size-independent properties."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    cfg = _configs(kw)[stage]
+    model = _model(P, params, kw)
+    pm = getattr(model, f"patchmatch_{stage}")
+    feats, proj, h, w = _fullsize_stage(P, stage, n_src, H, W, params, kw)
+    dmin, dmax = np.array([425.0], np.float32), np.array([935.0], np.float32)
+    gen = torch.Generator().manual_seed(1234)
+    noise = torch.rand(1, 48, h, w, generator=gen)
+    if stage == 3:
+        depth, vw = None, None
+    else:
+        depth = (425.0 + 510.0 * torch.rand(1, 1, h, w, generator=gen)).numpy()
+        vw = torch.rand(1, n_src, h, w, generator=gen).numpy()
+    dbg = []
+    with torch.no_grad():
+        out = pm(ref_feature=feats[0].to(DEV), src_features=[f.to(DEV) for f in feats[1:]], ref_proj=t(proj[:, 0]),
+                 src_projs=[t(proj[:, i]) for i in range(1, proj.shape[1])], depth_min=t(dmin), depth_max=t(dmax),
+                 depth=torch.empty(0, device=DEV) if depth is None else t(depth),
+                 view_weights=torch.empty(0, device=DEV) if vw is None else t(vw), noise=noise.to(DEV), debug=dbg)
+    torch.cuda.synchronize()
+    # --- properties that hold at any size
+    for rec in dbg:
+        prob = rec["score"]
+        assert torch.allclose(prob.sum(1), torch.ones_like(prob.sum(1)), atol=1e-5)
+        hyp = rec["depth_sample"]
+        assert float(hyp.min()) >= 425.0 * (1 - 1e-6) and float(hyp.max()) <= 935.0 * (1 + 1e-6)
+        if rec["propa_offsets"] is not None and not (stage == 1):
+            assert bool((hyp[:, 1:] >= hyp[:, :-1]).all()), "propagated hypotheses must be sorted ascending"
+        d = rec["depth"]
+        assert float(d.min()) >= 425.0 * (1 - 1e-5) and float(d.max()) <= 935.0 * (1 + 1e-5)
+        assert float(rec["view_weights"].min()) >= 0.0 and float(rec["view_weights"].max()) <= 1.0
+    # determinism: a second run is bit-identical
+    with torch.no_grad():
+        out2 = pm(ref_feature=feats[0].to(DEV), src_features=[f.to(DEV) for f in feats[1:]], ref_proj=t(proj[:, 0]),
+                  src_projs=[t(proj[:, i]) for i in range(1, proj.shape[1])], depth_min=t(dmin), depth_max=t(dmax),
+                  depth=torch.empty(0, device=DEV) if depth is None else t(depth),
+                  view_weights=torch.empty(0, device=DEV) if vw is None else t(vw), noise=noise.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip(out[0], out2[0])) and torch.equal(out[1], out2[1])
+    # --- oracle on the same inputs (offsets taken from the GPU conv so both sides sample the same neighbours)
+    otr = []
+    O.patchmatch_stage(cfg, params, feats[0].numpy(), [f.numpy() for f in feats[1:]], proj[:, 0],
+                       [proj[:, i] for i in range(1, proj.shape[1])], dmin, dmax, depth, vw, noise=noise.numpy(),
+                       propa_offsets=None if dbg[0]["propa_offsets"] is None else n(dbg[0]["propa_offsets"]),
+                       eval_offsets=n(dbg[0]["eval_offsets"]), trace=otr)
+    for it, (rec, orec) in enumerate(zip(dbg, otr)):
+        if it == 0:
+            assert GU.rel_err(n(rec["depth_sample"]), orec["depth_sample"]) < 2e-6
+            assert GU.abs_err(n(rec["similarity"]), orec["similarity"]) < 1e-4
+            if stage == 3:
+                mism = float((n(rec["view_weight_argmax"]) != orec["view_weight_argmax"]).mean())
+                assert mism == 0.0, mism
+        rel = np.abs(n(rec["depth"]) - orec["depth"]) / orec["depth"]
+        assert rel.max() < 1e-3, (it, float(rel.max()))
