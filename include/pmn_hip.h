@@ -10,7 +10,7 @@
  *   - all tensor arguments are DEVICE pointers to contiguous float32 buffers owned (and pre-allocated) by the
  *     caller; the library never allocates, never synchronises, and launches on `stream` (a hipStream_t; pass the
  *     caller's current stream, NULL = default stream);
- *   - arguments documented "host" (*_host) are small HOST arrays copied into the kernel-argument segment;
+ *   - arguments named *_host are small HOST arrays (neighbour tables) copied into the kernel-argument segment;
  *   - returns PMN_OK (0) or a negative PMN_ERR_* code; nothing is launched when an argument check fails;
  *   - one process drives one GPU; entry points are re-entrant and keep no global state.
  *
@@ -20,8 +20,9 @@
  *   per-view weight [B, N, h, w]
  *   offsets         [B, 2K, h, w]  output of the reference's propa_conv / eval_conv (channel 2k -> x, 2k+1 -> y)
  *   neighbour table host int[2K]   (dy,dx) pairs, reference models/patchmatch.py:331-392
- *   MLP block       host float[PMN_MLP_FLOATS]: w0[16][8] (row j holds G used entries, BN folded), t0[16],
- *                   w1[8][16] (BN folded), t1[8], w2[8], b2   -- see patchmatchnet_amd/params.py
+ *   MLP block       DEVICE float[PMN_MLP_FLOATS], BatchNorm folded, packed once per model by
+ *                   patchmatchnet_amd/params.py: 16 records of 20 floats, one per hidden unit j
+ *                   { w0[j][0..7] (first G used) | w1[0..7][j] | t0[j] | 3 pad }, then t1[8] | w2[8] | b2 | 3 pad
  */
 #ifndef PMN_HIP_H
 #define PMN_HIP_H
@@ -32,8 +33,8 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 1
-#define PMN_MLP_FLOATS 289
+#define PMN_ABI_VERSION 2
+#define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
 
@@ -57,7 +58,7 @@ int pmn_nchw_to_nhwc(const float *in, float *out, int B, int C, int h, int w, vo
  * normalised with (size-1)/2), group-wise correlation with the centre feature, MLP, sigmoid.
  * out_feature_weight [B,K,h,w].  C in {16,32,64}, G in {4,8} with C/G in {4,8}, K in {9,17}. */
 int pmn_feature_weight(const float *ref_nhwc, const float *eval_offsets, const int *eval_table_host,
-                       const float *mlp_host, int B, int C, int G, int K, int h, int w,
+                       const float *mlp, int B, int C, int G, int K, int h, int w,
                        float *out_feature_weight, void *stream);
 
 /* DepthInitialization.forward + Propagation.forward (reference models/patchmatch.py:53-94, 115-124), fused:
@@ -88,7 +89,7 @@ int pmn_init_hypotheses(const float *noise, const float *depth, int depth_shift,
  * The warped volume [B,C,D,h,w] is never materialised. */
 int pmn_warp_correlate(const float *ref_nhwc, const float *src_nhwc, const float *rel_proj,
                        const float *depth_sample, const float *view_weights_in, int vw_shift,
-                       const float *similarity_mlp_host, const float *pixelwise_mlp_host, int B, int N, int C,
+                       const float *similarity_mlp, const float *pixelwise_mlp, int B, int N, int C,
                        int G, int D, int h, int w, int hs, int ws, float *cost_out, float *view_weights_out,
                        int *vw_argmax_out, float *similarity_out, void *stream);
 

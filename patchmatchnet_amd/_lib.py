@@ -13,8 +13,8 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 1
-MLP_FLOATS = 289
+ABI_VERSION = 2
+MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
 
@@ -30,9 +30,9 @@ SIGNATURES = {
     "pmn_abi_version": [],
     "pmn_error_string": [_i],
     "pmn_nchw_to_nhwc": [_fp, _fp, _i, _i, _i, _i, _s],
-    "pmn_feature_weight": [_fp, _fp, _hp, _hp, _i, _i, _i, _i, _i, _i, _fp, _s],
+    "pmn_feature_weight": [_fp, _fp, _hp, _fp, _i, _i, _i, _i, _i, _i, _fp, _s],
     "pmn_init_hypotheses": [_fp, _fp, _i, _fp, _fp, _i, _f, _fp, _hp, _i, _i, _i, _i, _fp, _fp, _s],
-    "pmn_warp_correlate": [_fp, _fp, _fp, _fp, _fp, _i, _hp, _hp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _ip,
+    "pmn_warp_correlate": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _ip,
                            _fp, _s],
     "pmn_aggregate_regress": [_fp, _fp, _fp, _fp, _fp, _hp, _i, _f, _i, _i, _i, _i, _i, _fp, _fp, _s],
     "pmn_confidence": [_fp, _i, _i, _i, _i, _i, _i, _fp, _ip, _s],

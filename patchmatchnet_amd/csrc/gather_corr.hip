@@ -12,17 +12,21 @@
 //     (256/128/64 B at C = 64/32/16).  A lane owns one float4 channel quad; LPI = C/4 lanes cooperate on one
 //     (pixel, hypothesis) item and a wave covers 64/LPI consecutive pixels at the same hypothesis, so a wave-level
 //     corner load is one contiguous ~1 KB run of the source map whenever the homography is locally ~1 px/px.
-//   * a workgroup owns a tile of NPIX = 256/LPI consecutive pixels x all D hypotheses.  Per view:
-//       phase A  every thread projects (pixel, d) items and parks {texel offset, 4 corner weights} in LDS
-//                (the projection is done once per item, not once per lane);
-//       phase B  lane groups walk their pixel's D items: LDS broadcast of the record, 4 x global_load_dwordx4,
-//                bilinear blend, product with the (register-resident) reference quad, in-lane + one DPP step
-//                group reduction, view-weighted accumulation into an LDS tile [G][items];
-//       (PIXELWISE) the per-view similarity tile is pushed through PixelwiseNet (weights in SGPRs via kernarg),
-//                max over D by a 64-bit LDS atomic max (value bits | ~d  ->  first arg-max), then accumulated.
-//     Epilogue (phase C): divide by the view-weight sum, SimilarityNet / FeatureWeightNet MLP per item, coalesced
-//     store of cost[d][pixel].  The [C,D,h,w] warped volume and the per-view [G,D,h,w] similarity never touch HBM.
-//   * no MFMA: ~10 flop per gathered float, no dense contraction.
+//   * a workgroup owns a tile of NPIX = 256/LPI consecutive pixels x all D hypotheses and alternates two roles:
+//       item role   thread <-> (pixel, a few hypotheses): projects the items and parks {texel offset, 4 corner
+//                   weights} in LDS (phase A: the projection is done once per item, not once per lane); later runs
+//                   the pointwise MLPs on its items (weights broadcast from LDS, each weight row reused for all the
+//                   thread's items) and stores cost[d][pixel] coalesced;
+//       lane role   LPI lanes <-> pixel: walk the pixel's hypotheses (phase B): LDS broadcast of the record,
+//                   4 x global_load_dwordx4, bilinear blend, product with the register-resident reference quad,
+//                   in-lane + one DPP step group reduction.  With known view weights the per-(pixel,group,d)
+//                   sums over views accumulate in REGISTERS of the owning lane (the d loop is fully unrolled over
+//                   the compile-time bound DT) and reach LDS once, for the hand-over to the item role; with
+//                   PixelwiseNet each view's tile goes through LDS to the item role, which evaluates the net,
+//                   takes the max over D with a 64-bit LDS atomic max (value bits | ~d -> first arg-max) and keeps
+//                   the weighted sums in its own registers.
+//     The [C,D,h,w] warped volume and the per-view [G,D,h,w] similarity never touch HBM.
+//   * no MFMA: ~10 flop per gathered float, no dense contraction worth a matrix core (the MLPs are 16x8 / 8x16).
 #include <cstdlib>
 #include <cstring>
 
@@ -37,29 +41,136 @@ struct GatherArgs {
     const float* depth;    // [B,D,h,w]
     const float* offsets;  // [B,2K,h,w]   (MODE_NEIGHBOR)
     const float* vw_in;    // [B,N,h>>s,w>>s]
+    const float* mlp_a;    // device float[PMN_MLP_FLOATS]: similarity_net | feature_weight_net
+    const float* mlp_b;    // device float[PMN_MLP_FLOATS]: pixel_wise_net
     float* vw_out;         // [B,N,h,w]
     int* vw_argmax;        // [B,N,h,w] or null
     float* sim_out;        // [B,G,D,h,w] or null
     float* out;            // [B,D,h,w]
     int B, N, D, h, w, hs, ws, vw_shift, vchunk, ntiles;
     int table[2 * PMN_MAX_NEIGHBORS];
-    PmnMlp mlp_a;  // similarity_net | feature_weight_net
-    PmnMlp mlp_b;  // pixel_wise_net
 };
+
+#define MLP_LDS_FLOATS PMN_MLP_FLOATS  // 340: a float4 multiple
 
 __device__ __forceinline__ float pmn_pair_swap(float v) {
     // lane l <-> lane l^1 through DPP quad_perm [1,0,3,2]
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-template <int C, int G, int MODE>
-__global__ __launch_bounds__(PMN_BLOCK) void gather_corr_kernel(const GatherArgs a) {
-    constexpr int LPI = C / 4;           // lanes per (pixel, hypothesis) item
-    constexpr int NPIX = PMN_BLOCK / LPI;  // pixels per workgroup tile
-    constexpr int CG = C / G;            // channels per correlation group (4 or 8)
-    constexpr int LPG = CG / 4;          // lanes per group (1 or 2)
-    constexpr int PAD = 32 / G;          // LDS row padding: rows of different groups land on different banks
+// Pointwise MLP G -> 16 -> 8 -> 1 for NI items at once, weights read from LDS (uniform address = broadcast read).
+// Layers 1 and 2 are fused in a ROLLED loop over the 16 hidden units: unit j of every item is produced from weight row
+// j and immediately scattered into the 8 layer-2 accumulators with column j of the second weight matrix, so no array
+// of hidden activations or of weights stays live (a fully unrolled form makes hipcc hoist all 73 row loads and spill).
+// The packed block (params.py) is laid out for exactly this walk: per unit j one 20-float record
+//   [0..7] w0[j][g] (BN folded, g < G used) | [8..15] w1[k][j] (BN folded) | [16] t0[j] | pad
+// followed by t1[8] | w2[8] | b2.  Summation orders: layer 1 over g ascending, layer 2 over j ascending, layer 3 over
+// k ascending, bias added last -- the same as the oracle's.
+template <int G, int NI>
+__device__ __forceinline__ void mlp_from_lds(const float* __restrict__ W, const float (&x)[NI][G], float (&out)[NI]) {
+    float a1[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a1[i][k] = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+        const float4* rp = reinterpret_cast<const float4*>(W + 20 * j);
+        float w0[8], w1c[8];
+        {
+            const float4 r0 = rp[0];
+            w0[0] = r0.x; w0[1] = r0.y; w0[2] = r0.z; w0[3] = r0.w;
+            if (G == 8) {
+                const float4 r1 = rp[1];
+                w0[4] = r1.x; w0[5] = r1.y; w0[6] = r1.z; w0[7] = r1.w;
+            }
+            const float4 c0 = rp[2], c1 = rp[3];
+            w1c[0] = c0.x; w1c[1] = c0.y; w1c[2] = c0.z; w1c[3] = c0.w;
+            w1c[4] = c1.x; w1c[5] = c1.y; w1c[6] = c1.z; w1c[7] = c1.w;
+        }
+        const float t0 = W[20 * j + 16];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float acc = w0[0] * x[i][0];
+#pragma unroll
+            for (int g = 1; g < G; ++g) acc = fmaf(w0[g], x[i][g], acc);
+            const float hj = fmaxf(acc + t0, 0.0f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a1[i][k] = fmaf(w1c[k], hj, a1[i][k]);
+        }
+    }
+    const float4 ta = reinterpret_cast<const float4*>(W + 320)[0], tb = reinterpret_cast<const float4*>(W + 320)[1];
+    const float4 wa = reinterpret_cast<const float4*>(W + 328)[0], wb = reinterpret_cast<const float4*>(W + 328)[1];
+    const float t1[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    const float w2[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    const float b2 = W[336];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float acc = w2[0] * fmaxf(a1[i][0] + t1[0], 0.0f);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) acc = fmaf(w2[k], fmaxf(a1[i][k] + t1[k], 0.0f), acc);
+        out[i] = acc + b2;
+    }
+}
+
+// NIT items in chunks of NI
+template <int G, int NIT, int NI>
+__device__ __forceinline__ void mlp_items(const float* __restrict__ W, const float (&x)[NIT][G], float (&out)[NIT]) {
+    static_assert(NIT % NI == 0, "chunk must divide the item count");
+#pragma unroll
+    for (int c = 0; c < NIT / NI; ++c) {
+        float xc[NI][G], oc[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) xc[i][g] = x[c * NI + i][g];
+        mlp_from_lds<G, NI>(W, xc, oc);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) out[c * NI + i] = oc[i];
+    }
+}
+
+__device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
+#pragma clang fp contract(off)
+    return acc + a * b;  // two roundings, like the reference's separate mul and add kernels
+}
+
+// One (pixel, hypothesis) item of the lane role: returns this lane's group-correlation value (valid in the owner lane
+// of each group; with 8-channel groups both lanes of the pair hold it).
+template <int LPI, int LPG, int CG>
+__device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, const float4 w4, const int off, const int ws,
+                                             const float4 refq) {
+    const float4* bp = srcv + (size_t)off * LPI;
+    const float4 t00 = bp[0];
+    const float4 t01 = bp[LPI];
+    const float4 t10 = bp[(size_t)ws * LPI];
+    const float4 t11 = bp[(size_t)ws * LPI + LPI];
+    float4 val;
+    val.x = fmaf(t11.x, w4.w, fmaf(t10.x, w4.z, fmaf(t01.x, w4.y, t00.x * w4.x)));
+    val.y = fmaf(t11.y, w4.w, fmaf(t10.y, w4.z, fmaf(t01.y, w4.y, t00.y * w4.x)));
+    val.z = fmaf(t11.z, w4.w, fmaf(t10.z, w4.z, fmaf(t01.z, w4.y, t00.z * w4.x)));
+    val.w = fmaf(t11.w, w4.w, fmaf(t10.w, w4.z, fmaf(t01.w, w4.y, t00.w * w4.x)));
+    float s = fmaf(val.w, refq.w, fmaf(val.z, refq.z, fmaf(val.y, refq.y, val.x * refq.x)));
+    if (LPG == 2) s += pmn_pair_swap(s);
+    return s * (1.0f / CG);
+}
+
+// __launch_bounds__ second argument = minimum waves per SIMD: 4 (<= 128 VGPRs, 4 workgroups per CU) keeps enough
+// waves resident to cover the gather latency; the PixelwiseNet variant is LDS-limited to 3 workgroups per CU anyway.
+template <int C, int G, int MODE, int DT>
+__global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void gather_corr_kernel(const GatherArgs a) {
+    constexpr int LPI = C / 4;               // lanes per (pixel, hypothesis) item
+    constexpr int NPIX = PMN_BLOCK / LPI;    // pixels per workgroup tile
+    constexpr int CG = C / G;                // channels per correlation group (4 or 8)
+    constexpr int LPG = CG / 4;              // lanes per group (1 or 2)
+    constexpr int PAD = 32 / G;              // LDS row padding: rows of different groups land on different banks
+    constexpr int DSTEP = PMN_BLOCK / NPIX;  // item role: a thread's hypotheses are dA0, dA0+DSTEP, ...
+    constexpr int NIT = DT / DSTEP;          // item role: hypotheses per thread
+    constexpr int NI_MAX = (MODE == MODE_PIXELWISE) ? 2 : 4;  // PIXELWISE also keeps NIT*G running sums live
+    constexpr int NI = NIT < NI_MAX ? NIT : NI_MAX;            // MLP evaluated for NI items at a time
+    constexpr int DCH = 32;                  // PIXELWISE / NEIGHBOR: hypotheses per phase-A/B round
     static_assert(CG == 4 || CG == 8, "group size must be 4 or 8 channels");
+    static_assert(NIT >= 1, "DT must cover at least one hypothesis per item-role thread");
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -70,20 +181,22 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_corr_kernel(const GatherArgs
     const int SS = items + PAD;
     const int p0 = tile * NPIX;
     const int vchunk = (MODE == MODE_VIEWS) ? a.vchunk : 1;
+    const int rcap = (MODE == MODE_VIEWS) ? vchunk * items : NPIX * min(D, DCH);
 
     extern __shared__ float4 smem4[];
-    float4* recw = smem4;                                         // [vchunk][items]
-    int* reco = reinterpret_cast<int*>(recw + vchunk * items);    // [vchunk][items]
-    float* sim_sum = reinterpret_cast<float*>(reco + vchunk * items);  // [G][SS]
-    float* sim_v = sim_sum + G * SS;                              // [G][SS]           (PIXELWISE)
-    unsigned long long* vwkey = reinterpret_cast<unsigned long long*>(sim_v + (MODE == MODE_PIXELWISE ? G * SS : 0) +
-                                                                      ((G * SS) & 1));  // 8-byte aligned
-    float* wsum = reinterpret_cast<float*>(vwkey + NPIX);         // [NPIX]            (PIXELWISE)
-    int* tab = reinterpret_cast<int*>(wsum + NPIX);               // [2K]              (NEIGHBOR)
+    float4* recw = smem4;                                         // [rcap] corner weights
+    int* reco = reinterpret_cast<int*>(recw + rcap);              // [rcap] texel offsets
+    float* simt = reinterpret_cast<float*>(reco + rcap);          // [G][SS] similarity tile
+    float* wlds_a = simt + ((G * SS + 3) & ~3);                   // MLP a weights (16-byte aligned)
+    float* wlds_b = wlds_a + MLP_LDS_FLOATS;                      // MLP b weights           (PIXELWISE)
+    unsigned long long* vwkey = reinterpret_cast<unsigned long long*>(wlds_b + MLP_LDS_FLOATS);  // [NPIX]
+    int* tab = reinterpret_cast<int*>(vwkey + NPIX);              // [2K]                    (NEIGHBOR)
 
     // ---- prologue -------------------------------------------------------------------------------------------
-    for (int i = tid; i < G * SS; i += PMN_BLOCK) sim_sum[i] = 0.0f;
-    if (MODE == MODE_PIXELWISE && tid < NPIX) wsum[tid] = 1e-5f;
+    for (int i = tid; i < PMN_MLP_FLOATS; i += PMN_BLOCK) {
+        wlds_a[i] = a.mlp_a[i];
+        if (MODE == MODE_PIXELWISE) wlds_b[i] = a.mlp_b[i];
+    }
     if (MODE == MODE_NEIGHBOR) {
         // static indices only: a dynamic index into the by-value kernarg struct would spill it to scratch
 #pragma unroll
@@ -91,13 +204,13 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_corr_kernel(const GatherArgs
             if (tid == i) tab[i] = a.table[i];
     }
 
-    // phase-A role: a fixed pixel of the tile, hypotheses dA0, dA0 + 256/NPIX, ...
+    // item role: a fixed pixel of the tile, hypotheses dA0 + j*DSTEP
     const int pixA = tid % NPIX, dA0 = tid / NPIX;
     const int pA = p0 + pixA;
     const bool okA = pA < hw;
     const int yA = okA ? pA / w : 0, xA = okA ? pA - yA * w : 0;
 
-    // phase-B role: lane lc of the lane group that owns pixel `grp` of the tile
+    // lane role: lane lc of the lane group that owns pixel `grp` of the tile
     const int grp = tid / LPI, lc = tid % LPI;
     const int pB = p0 + grp;
     const bool okB = pB < hw;
@@ -106,139 +219,191 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_corr_kernel(const GatherArgs
     const int yB = okB ? pB / w : 0, xB = okB ? pB - yB * w : 0;
     const int wv = w >> a.vw_shift, hwv = (h >> a.vw_shift) * wv;
     const int vw_idx = (yB >> a.vw_shift) * wv + (xB >> a.vw_shift);
+    const bool owner = (lc % LPG) == 0;
+    const int gB = lc / LPG;
 
-    if (MODE == MODE_NEIGHBOR) __syncthreads();  // tab visible
-
-    for (int v0 = 0; v0 < N; v0 += vchunk) {
-        const int nv = min(vchunk, N - v0);
-        // ---- phase A: project items, park tap records in LDS ----------------------------------------------------
-        if (MODE == MODE_PIXELWISE && tid < NPIX) vwkey[tid] = 0ull;
-        for (int vc = 0; vc < nv; ++vc) {
-            const float* P = a.proj + ((size_t)b * N + (v0 + vc)) * 16;
-            for (int d = dA0; d < D; d += PMN_BLOCK / NPIX) {
-                PmnTaps t;
-                t.off = 0;
-                t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
-                if (okA) {
-                    float ix, iy;
-                    if (MODE == MODE_NEIGHBOR) {
-                        const float ox = a.offsets[((size_t)b * 2 * D + 2 * d) * hw + pA];
-                        const float oy = a.offsets[((size_t)b * 2 * D + 2 * d + 1) * hw + pA];
-                        pmn_neighbor_position((float)xA, (float)yA, tab[2 * d], tab[2 * d + 1], ox, oy, h, w, ix, iy);
-                    } else {
-                        const float dep = a.depth[((size_t)b * D + d) * hw + pA];
-                        pmn_warp_position(P, (float)xA, (float)yA, dep, h, w, hs, ws, ix, iy);
-                    }
-                    t = pmn_make_taps(ix, iy, hs, ws);
-                }
-                const int i = vc * items + d * NPIX + pixA;
-                recw[i] = make_float4(t.w00, t.w01, t.w10, t.w11);
-                reco[i] = t.off;
-            }
-        }
-        __syncthreads();
-
-        // ---- phase B: gather + correlate ----------------------------------------------------------------------
-        for (int vc = 0; vc < nv; ++vc) {
-            const int v = v0 + vc;
-            const float4* srcv = reinterpret_cast<const float4*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
-                                 ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * LPI + lc;
-            float vw = 1.0f;
-            if (MODE == MODE_VIEWS) vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
-            const float4* rw = recw + vc * items + grp;
-            const int* ro = reco + vc * items + grp;
-#pragma unroll 4
-            for (int d = 0; d < D; ++d) {
-                const float4 w4 = rw[d * NPIX];
-                const int off = ro[d * NPIX];
-                const float4* bp = srcv + (size_t)off * LPI;
-                const float4 t00 = bp[0];
-                const float4 t01 = bp[LPI];
-                const float4 t10 = bp[(size_t)ws * LPI];
-                const float4 t11 = bp[(size_t)ws * LPI + LPI];
-                float4 val;
-                val.x = fmaf(t11.x, w4.w, fmaf(t10.x, w4.z, fmaf(t01.x, w4.y, t00.x * w4.x)));
-                val.y = fmaf(t11.y, w4.w, fmaf(t10.y, w4.z, fmaf(t01.y, w4.y, t00.y * w4.x)));
-                val.z = fmaf(t11.z, w4.w, fmaf(t10.z, w4.z, fmaf(t01.z, w4.y, t00.z * w4.x)));
-                val.w = fmaf(t11.w, w4.w, fmaf(t10.w, w4.z, fmaf(t01.w, w4.y, t00.w * w4.x)));
-                float s = fmaf(val.w, refq.w, fmaf(val.z, refq.z, fmaf(val.y, refq.y, val.x * refq.x)));
-                if (LPG == 2) s += pmn_pair_swap(s);
-                s *= (1.0f / CG);
-                if (lc % LPG == 0) {
-                    const int idx = (lc / LPG) * SS + d * NPIX + grp;
-                    if (MODE == MODE_VIEWS) {
-                        atomicAdd(&sim_sum[idx], s * vw);  // ds_add_f32, one owner lane per address
-                    } else if (MODE == MODE_PIXELWISE) {
-                        sim_v[idx] = s;
-                    } else {
-                        sim_sum[idx] = s;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        if (MODE == MODE_PIXELWISE) {
-            // ---- PixelwiseNet on this view's similarity tile; max over D per pixel ----------------------------------
-            const int v = v0;
-            for (int d = dA0; d < D; d += PMN_BLOCK / NPIX) {
-                const int i = d * NPIX + pixA;
-                float x[G];
+    // phase A for one view / hypothesis range [d_lo, d_hi): records land at rec_base + (d - d_lo)*NPIX + pixA
+    auto phase_a = [&](const float* P, int d_lo, int d_hi, int rec_base) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) x[g] = sim_v[g * SS + i];
-                const float r = pmn_sigmoid(pmn_mlp_eval<G>(a.mlp_b, x));
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(r) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
-                atomicMax(&vwkey[pixA], key);
-            }
-            __syncthreads();
-            {
-#pragma clang fp contract(off)
-                const unsigned long long key = vwkey[pixA];
-                const float vwp = __uint_as_float((unsigned)(key >> 32));
-                for (int d = dA0; d < D; d += PMN_BLOCK / NPIX) {
-                    const int i = d * NPIX + pixA;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sim_sum[g * SS + i] = sim_sum[g * SS + i] + sim_v[g * SS + i] * vwp;
+        for (int j = 0; j < NIT; ++j) {
+            const int d = dA0 + j * DSTEP;
+            if (d < d_lo || d >= d_hi) continue;
+            PmnTaps t;
+            t.off = 0;
+            t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+            if (okA) {
+                float ix, iy;
+                if (MODE == MODE_NEIGHBOR) {
+                    const float ox = a.offsets[((size_t)b * 2 * D + 2 * d) * hw + pA];
+                    const float oy = a.offsets[((size_t)b * 2 * D + 2 * d + 1) * hw + pA];
+                    pmn_neighbor_position((float)xA, (float)yA, tab[2 * d], tab[2 * d + 1], ox, oy, h, w, ix, iy);
+                } else {
+                    const float dep = a.depth[((size_t)b * D + d) * hw + pA];
+                    pmn_warp_position(P, (float)xA, (float)yA, dep, h, w, hs, ws, ix, iy);
                 }
-                if (tid < NPIX) {
-                    wsum[tid] = wsum[tid] + vwp;
-                    if (okA) {
-                        const size_t o = ((size_t)b * N + v) * hw + pA;
-                        a.vw_out[o] = vwp;
-                        if (a.vw_argmax) a.vw_argmax[o] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-                    }
-                }
+                t = pmn_make_taps(ix, iy, hs, ws);
             }
-            __syncthreads();
+            const int i = rec_base + (d - d_lo) * NPIX + pixA;
+            recw[i] = make_float4(t.w00, t.w01, t.w10, t.w11);
+            reco[i] = t.off;
         }
-    }
+    };
 
-    // ---- phase C: normalise by the view-weight sum, pointwise MLP, store -------------------------------------------
-    if (!okA) return;
-    float wtot = 1.0f;
     if (MODE == MODE_VIEWS) {
-        wtot = 1e-5f;
+        // ================= known view weights: accumulate over views in registers =======================================
+        float acc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[d] = 0.0f;
+        for (int v0 = 0; v0 < N; v0 += vchunk) {
+            const int nv = min(vchunk, N - v0);
+            for (int vc = 0; vc < nv; ++vc) phase_a(a.proj + ((size_t)b * N + (v0 + vc)) * 16, 0, D, vc * items);
+            __syncthreads();
+            for (int vc = 0; vc < nv; ++vc) {
+                const int v = v0 + vc;
+                const float4* srcv = reinterpret_cast<const float4*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * LPI + lc;
+                const float vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
+                const float4* rw = recw + vc * items + grp;
+                const int* ro = reco + vc * items + grp;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    if (d < D) {
+                        const float s = gather_item<LPI, LPG, CG>(srcv, rw[d * NPIX], ro[d * NPIX], ws, refq);
+                        acc[d] = mul_add_unfused(acc[d], s, vw);
+                    }
+                    // keep at most 4 items (16 x dwordx4) in flight: without the fence the scheduler hoists every load
+                    // of the unrolled loop and the register allocator spills
+                    if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+        if (owner) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+                if (d < D) simt[gB * SS + d * NPIX + grp] = acc[d];
+        }
+        __syncthreads();
+        if (!okA) return;
+        float wtot = 1e-5f;
         const int vwi = (yA >> a.vw_shift) * wv + (xA >> a.vw_shift);
         for (int v = 0; v < N; ++v) wtot += a.vw_in[((size_t)b * N + v) * hwv + vwi];
-    } else if (MODE == MODE_PIXELWISE) {
-        wtot = wsum[pixA];
+        float x[NIT][G], o[NIT];
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int d = min(dA0 + j * DSTEP, D - 1);
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[j][g] = simt[g * SS + d * NPIX + pixA] / wtot;
+        }
+        mlp_items<G, NIT, NI>(wlds_a, x, o);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int d = dA0 + j * DSTEP;
+            if (d < D) {
+                if (a.sim_out) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = x[j][g];
+                }
+                a.out[((size_t)b * D + d) * hw + pA] = o[j];
+            }
+        }
+        return;
     }
-    for (int d = dA0; d < D; d += PMN_BLOCK / NPIX) {
-        const int i = d * NPIX + pixA;
-        float x[G];
+
+    // ================= PIXELWISE (N views, view weights computed here) / NEIGHBOR (one pseudo view) ======================
+    float ssum[NIT][G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            x[g] = sim_sum[g * SS + i];
-            if (MODE != MODE_NEIGHBOR) x[g] = x[g] / wtot;
-        }
-        if (MODE != MODE_NEIGHBOR && a.sim_out) {
+    for (int j = 0; j < NIT; ++j)
 #pragma unroll
-            for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = x[g];
+        for (int g = 0; g < G; ++g) ssum[j][g] = 0.0f;
+    float wsum = 1e-5f;
+    __syncthreads();  // tab / MLP weights visible
+
+    for (int v = 0; v < N; ++v) {
+        if (MODE == MODE_PIXELWISE && tid < NPIX) vwkey[tid] = 0ull;
+        const float* P = a.proj + ((size_t)b * N + v) * 16;
+        const float4* srcv = reinterpret_cast<const float4*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
+                             ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * LPI + lc;
+        for (int dc0 = 0; dc0 < D; dc0 += DCH) {
+            const int dc1 = min(D, dc0 + DCH);
+            phase_a(P, dc0, dc1, 0);
+            __syncthreads();
+            const float4* rw = recw + grp;
+            const int* ro = reco + grp;
+#pragma unroll 4
+            for (int d = dc0; d < dc1; ++d) {
+                const float s = gather_item<LPI, LPG, CG>(srcv, rw[(d - dc0) * NPIX], ro[(d - dc0) * NPIX], ws, refq);
+                if (owner) simt[gB * SS + d * NPIX + grp] = s;
+            }
+            __syncthreads();
         }
-        float o = pmn_mlp_eval<G>(a.mlp_a, x);
-        if (MODE == MODE_NEIGHBOR) o = pmn_sigmoid(o);
-        a.out[((size_t)b * D + d) * hw + pA] = o;
+        // item role: this view's similarities of my items
+        float x[NIT][G];
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int d = min(dA0 + j * DSTEP, D - 1);
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[j][g] = simt[g * SS + d * NPIX + pixA];
+        }
+        if (MODE == MODE_NEIGHBOR) {
+            if (!okA) return;
+            float o[NIT];
+            mlp_items<G, NIT, NI>(wlds_a, x, o);
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int d = dA0 + j * DSTEP;
+                if (d < D) a.out[((size_t)b * D + d) * hw + pA] = pmn_sigmoid(o[j]);
+            }
+            return;
+        }
+        // PixelwiseNet + max over D (first arg-max on ties through the ~d low word)
+        {
+            float r[NIT];
+            mlp_items<G, NIT, NI>(wlds_b, x, r);
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int d = dA0 + j * DSTEP;
+                if (d < D) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(pmn_sigmoid(r[j])) << 32) |
+                                                   (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
+                    best = key > best ? key : best;
+                }
+            }
+            atomicMax(&vwkey[pixA], best);
+        }
+        __syncthreads();
+        const unsigned long long key = vwkey[pixA];
+        const float vwp = __uint_as_float((unsigned)(key >> 32));
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+#pragma unroll
+            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], x[j][g], vwp);
+        wsum += vwp;
+        if (tid < NPIX && okA) {
+            const size_t o = ((size_t)b * N + v) * hw + pA;
+            a.vw_out[o] = vwp;
+            if (a.vw_argmax) a.vw_argmax[o] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        }
+        __syncthreads();  // vwkey / simt are rewritten by the next view
+    }
+
+    if (!okA) return;
+    float o[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ssum[j][g] = ssum[j][g] / wsum;
+    mlp_items<G, NIT, NI>(wlds_a, ssum, o);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int d = dA0 + j * DSTEP;
+        if (d < D) {
+            if (a.sim_out) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = ssum[j][g];
+            }
+            a.out[((size_t)b * D + d) * hw + pA] = o[j];
+        }
     }
 }
 
@@ -249,7 +414,7 @@ static int env_int(const char* name, int dflt) {
     return s ? atoi(s) : dflt;
 }
 
-template <int C, int G, int MODE>
+template <int C, int G, int MODE, int DT>
 static int launch_gather(GatherArgs& a, hipStream_t stream) {
     constexpr int LPI = C / 4, NPIX = PMN_BLOCK / LPI, PAD = 32 / G;
     const int hw = a.h * a.w;
@@ -257,10 +422,11 @@ static int launch_gather(GatherArgs& a, hipStream_t stream) {
     if (MODE != MODE_VIEWS) a.vchunk = 1;
     a.vchunk = a.vchunk < 1 ? 1 : (a.vchunk > a.N ? a.N : a.vchunk);
     const int items = NPIX * a.D, SS = items + PAD;
-    size_t lds = (size_t)a.vchunk * items * 20 + (size_t)G * SS * 4 * (MODE == MODE_PIXELWISE ? 2 : 1) + 8 /*align*/ +
-                 NPIX * 12 + 2 * PMN_MAX_NEIGHBORS * 4;
+    const int rcap = (MODE == MODE_VIEWS) ? a.vchunk * items : NPIX * (a.D < 32 ? a.D : 32);
+    size_t lds = (size_t)rcap * 20 + (size_t)((G * SS + 3) & ~3) * 4 + 2 * MLP_LDS_FLOATS * 4 + NPIX * 8 +
+                 2 * PMN_MAX_NEIGHBORS * 4;
     lds = (lds + 15) & ~(size_t)15;
-    auto kern = gather_corr_kernel<C, G, MODE>;
+    auto kern = gather_corr_kernel<C, G, MODE, DT>;
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -272,23 +438,40 @@ static int launch_gather(GatherArgs& a, hipStream_t stream) {
     return PMN_OK;
 }
 
+// DT = compile-time bound of the hypothesis loop: next power of two >= D, and >= the item-role stride C/4
+template <int C, int G, int MODE>
+static int dispatch_depth(GatherArgs& a, hipStream_t stream) {
+    constexpr int DSTEP = C / 4;  // = PMN_BLOCK / NPIX
+    if constexpr (MODE == MODE_PIXELWISE) {
+        return launch_gather<C, G, MODE, 64>(a, stream);
+    } else if constexpr (MODE == MODE_NEIGHBOR) {  // K = 9 or 17 neighbours
+        if (a.D <= 16) return launch_gather<C, G, MODE, 16>(a, stream);
+        return launch_gather<C, G, MODE, 32>(a, stream);
+    } else {
+        if constexpr (DSTEP <= 8) {
+            if (a.D <= 8) return launch_gather<C, G, MODE, 8>(a, stream);
+        }
+        if (a.D <= 16) return launch_gather<C, G, MODE, 16>(a, stream);
+        if (a.D <= 32) return launch_gather<C, G, MODE, 32>(a, stream);
+        return launch_gather<C, G, MODE, 64>(a, stream);
+    }
+}
+
 template <int MODE>
 static int dispatch_gather(GatherArgs& a, int C, int G, hipStream_t stream) {
-    if (C == 64 && G == 8) return launch_gather<64, 8, MODE>(a, stream);
-    if (C == 32 && G == 8) return launch_gather<32, 8, MODE>(a, stream);
-    if (C == 16 && G == 4) return launch_gather<16, 4, MODE>(a, stream);
+    if (C == 64 && G == 8) return dispatch_depth<64, 8, MODE>(a, stream);
+    if (C == 32 && G == 8) return dispatch_depth<32, 8, MODE>(a, stream);
+    if (C == 16 && G == 4) return dispatch_depth<16, 4, MODE>(a, stream);
     return PMN_ERR_SHAPE;
 }
 
-static void load_mlp(PmnMlp& dst, const float* host) { memcpy(&dst, host, sizeof(PmnMlp)); }
-
 extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, const float* rel_proj,
                                   const float* depth_sample, const float* view_weights_in, int vw_shift,
-                                  const float* similarity_mlp_host, const float* pixelwise_mlp_host, int B, int N, int C,
-                                  int G, int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
+                                  const float* similarity_mlp, const float* pixelwise_mlp, int B, int N, int C, int G,
+                                  int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
                                   int* vw_argmax_out, float* similarity_out, void* stream) {
-    if (!ref_nhwc || !src_nhwc || !rel_proj || !depth_sample || !similarity_mlp_host || !cost_out) return PMN_ERR_ARG;
-    if (!view_weights_in && (!pixelwise_mlp_host || !view_weights_out)) return PMN_ERR_ARG;
+    if (!ref_nhwc || !src_nhwc || !rel_proj || !depth_sample || !similarity_mlp || !cost_out) return PMN_ERR_ARG;
+    if (!view_weights_in && (!pixelwise_mlp || !view_weights_out)) return PMN_ERR_ARG;
     if (B < 1 || N < 1 || D < 1 || h < 2 || w < 2 || hs < 2 || ws < 2 || vw_shift < 0 || vw_shift > 2) return PMN_ERR_ARG;
     if (D > PMN_MAX_DEPTH) return PMN_ERR_SHAPE;
     if ((h | w) & ((1 << vw_shift) - 1)) return PMN_ERR_ARG;
@@ -299,6 +482,8 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     a.proj = rel_proj;
     a.depth = depth_sample;
     a.vw_in = view_weights_in;
+    a.mlp_a = similarity_mlp;
+    a.mlp_b = pixelwise_mlp;
     a.vw_out = view_weights_out;
     a.vw_argmax = vw_argmax_out;
     a.sim_out = similarity_out;
@@ -306,16 +491,14 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     a.B = B; a.N = N; a.D = D; a.h = h; a.w = w; a.hs = hs; a.ws = ws;
     a.vw_shift = vw_shift;
     a.vchunk = env_int("PMN_VCHUNK", 2);
-    load_mlp(a.mlp_a, similarity_mlp_host);
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
-    load_mlp(a.mlp_b, pixelwise_mlp_host);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }
 
 extern "C" int pmn_feature_weight(const float* ref_nhwc, const float* eval_offsets, const int* eval_table_host,
-                                  const float* mlp_host, int B, int C, int G, int K, int h, int w,
-                                  float* out_feature_weight, void* stream) {
-    if (!ref_nhwc || !eval_offsets || !eval_table_host || !mlp_host || !out_feature_weight) return PMN_ERR_ARG;
+                                  const float* mlp, int B, int C, int G, int K, int h, int w, float* out_feature_weight,
+                                  void* stream) {
+    if (!ref_nhwc || !eval_offsets || !eval_table_host || !mlp || !out_feature_weight) return PMN_ERR_ARG;
     if (B < 1 || h < 2 || w < 2) return PMN_ERR_ARG;
     if (K < 1 || K > PMN_MAX_NEIGHBORS) return PMN_ERR_SHAPE;
     GatherArgs a;
@@ -323,10 +506,10 @@ extern "C" int pmn_feature_weight(const float* ref_nhwc, const float* eval_offse
     a.ref = ref_nhwc;
     a.src = ref_nhwc;
     a.offsets = eval_offsets;
+    a.mlp_a = mlp;
     a.out = out_feature_weight;
     a.B = B; a.N = 1; a.D = K; a.h = h; a.w = w; a.hs = h; a.ws = w;
     a.vchunk = 1;
     for (int i = 0; i < 2 * K; ++i) a.table[i] = eval_table_host[i];
-    load_mlp(a.mlp_a, mlp_host);
     return dispatch_gather<MODE_NEIGHBOR>(a, C, G, (hipStream_t)stream);
 }

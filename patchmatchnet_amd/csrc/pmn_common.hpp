@@ -15,45 +15,6 @@
 
 #define PMN_BLOCK 256
 
-// ---- pointwise MLP G -> 16 -> 8 -> 1 (ConvBnReLU3D x2 + Conv3d; reference models/module.py:43-72) ----------
-// BatchNorm (eval) is folded on the host in fp64: w' = w * gamma/sqrt(var+eps), t = beta - mean*gamma/sqrt(var+eps).
-// The struct travels in the kernarg segment, so the weights are scalar loads / SGPR operands.
-struct PmnMlp {
-    float w0[16 * 8];  // [16][G] row-major, only the first 16*G entries used
-    float t0[16];
-    float w1[8 * 16];
-    float t1[8];
-    float w2[8];
-    float b2;
-};
-static_assert(sizeof(PmnMlp) == PMN_MLP_FLOATS * sizeof(float), "host/device MLP packing mismatch");
-
-template <int G>
-__device__ __forceinline__ float pmn_mlp_eval(const PmnMlp& P, const float (&x)[G]) {
-    float h0[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float acc = P.w0[j * G] * x[0];
-#pragma unroll
-        for (int g = 1; g < G; ++g) acc = fmaf(P.w0[j * G + g], x[g], acc);
-        acc += P.t0[j];
-        h0[j] = fmaxf(acc, 0.0f);
-    }
-    float h1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float acc = P.w1[j * 16] * h0[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) acc = fmaf(P.w1[j * 16 + i], h0[i], acc);
-        acc += P.t1[j];
-        h1[j] = fmaxf(acc, 0.0f);
-    }
-    float acc = P.w2[0] * h1[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) acc = fmaf(P.w2[i], h1[i], acc);
-    return acc + P.b2;
-}
-
 __device__ __forceinline__ float pmn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- bilinear tap set --------------------------------------------------------------------------------------

@@ -98,7 +98,14 @@ def stack_sources_nhwc(src_features: Sequence[torch.Tensor]) -> torch.Tensor:
     return buf
 
 
-def feature_weight(ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray, mlp: np.ndarray,
+def _mlp_dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    _dev(t, name)
+    if t.numel() != _lib.MLP_FLOATS:
+        raise PmnError(f"{name}: expected a packed MLP block of {_lib.MLP_FLOATS} floats")
+    return t
+
+
+def feature_weight(ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray, mlp: torch.Tensor,
                    G: int) -> torch.Tensor:
     """FeatureWeightNet (reference models/patchmatch.py:603-624) -> [B,K,h,w]."""
     _dev(ref_nhwc, "ref_nhwc")
@@ -108,10 +115,11 @@ def feature_weight(ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np
     if tuple(eval_offsets.shape) != (B, 2 * K, h, w):
         raise PmnError("feature_weight: eval_offsets must be [B,2K,h,w]")
     tab, tab_p = _host_i32(table, 2 * K, "table")
-    blk, blk_p = _host_f32(mlp, _lib.MLP_FLOATS, "mlp")
+    _mlp_dev(mlp, "mlp")
     out = torch.empty((B, K, h, w), dtype=torch.float32, device=ref_nhwc.device)
     with torch.cuda.device(ref_nhwc.device):
-        check(_lib.lib().pmn_feature_weight(ref_nhwc.data_ptr(), eval_offsets.data_ptr(), tab_p, blk_p, B, C, G, K, h, w,
+        check(_lib.lib().pmn_feature_weight(ref_nhwc.data_ptr(), eval_offsets.data_ptr(), tab_p, mlp.data_ptr(), B, C, G,
+                                            K, h, w,
                                             out.data_ptr(), _stream(out)), "pmn_feature_weight")
     return out
 
@@ -162,8 +170,8 @@ def init_hypotheses(noise: Optional[torch.Tensor], depth: Optional[torch.Tensor]
 
 
 def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: torch.Tensor, depth_sample: torch.Tensor,
-                   view_weights: Optional[torch.Tensor], vw_shift: int, similarity_mlp: np.ndarray,
-                   pixelwise_mlp: Optional[np.ndarray], G: int, want_similarity: bool = False,
+                   view_weights: Optional[torch.Tensor], vw_shift: int, similarity_mlp: torch.Tensor,
+                   pixelwise_mlp: Optional[torch.Tensor], G: int, want_similarity: bool = False,
                    want_argmax: bool = False):
     """The fused warp + gather + group-correlation + view aggregation + SimilarityNet-MLP kernel.
 
@@ -179,8 +187,8 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
     if Bs != B or Cs != C or tuple(depth_sample.shape) != (B, D, h, w) or tuple(rel_proj.shape) != (B, N, 4, 4):
         raise PmnError("warp_correlate: inconsistent shapes")
     dev = ref_nhwc.device
-    sim_blk, sim_p = _host_f32(similarity_mlp, _lib.MLP_FLOATS, "similarity_mlp")
-    pix_blk, pix_p, vw_out, argmax = None, None, None, None
+    sim_p = _mlp_dev(similarity_mlp, "similarity_mlp").data_ptr()
+    pix_p, vw_out, argmax = None, None, None
     if view_weights is not None:
         _dev(view_weights, "view_weights")
         if tuple(view_weights.shape) != (B, N, h >> vw_shift, w >> vw_shift):
@@ -188,7 +196,7 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
     else:
         if pixelwise_mlp is None:
             raise PmnError("warp_correlate: pixelwise_mlp required when view_weights is None")
-        pix_blk, pix_p = _host_f32(pixelwise_mlp, _lib.MLP_FLOATS, "pixelwise_mlp")
+        pix_p = _mlp_dev(pixelwise_mlp, "pixelwise_mlp").data_ptr()
         vw_out = torch.empty((B, N, h, w), dtype=torch.float32, device=dev)
         if want_argmax:
             argmax = torch.empty((B, N, h, w), dtype=torch.int32, device=dev)

@@ -1,8 +1,8 @@
 """Host-side packing of the learned weights the kernels take through the kernel-argument segment.
 
-MLP block layout (include/pmn_hip.h, PMN_MLP_FLOATS = 289 float32):
-    w0[16][8] | t0[16] | w1[8][16] | t1[8] | w2[8] | b2
-Row j of w0 holds its G used entries contiguously at [j*G, j*G+G) (so the kernel indexes w0[j*G+g]).
+MLP block layout (include/pmn_hip.h, PMN_MLP_FLOATS = 340 float32), ordered for the kernels' fused layer-1/2 walk:
+    16 records of 20 floats, one per hidden unit j:  w0[j][0..7] (first G used) | w1[0..7][j] | t0[j] | 3 pad
+    then  t1[8] | w2[8] | b2 | 3 pad
 BatchNorm3d (eval mode, eps = 1e-5; reference models/module.py:43-72) is folded in float64 and rounded once:
     scale = gamma / sqrt(var + eps);  w' = w * scale;  t = beta - mean * scale
 """
@@ -23,7 +23,7 @@ def _np64(t: torch.Tensor) -> np.ndarray:
 
 
 def pack_mlp(conv0_w, bn0, conv1_w, bn1, last_w, last_b, eps: float = BN_EPS) -> np.ndarray:
-    """bn0 / bn1 = (weight, bias, running_mean, running_var) tensors.  Returns float32[289]."""
+    """bn0 / bn1 = (weight, bias, running_mean, running_var) tensors.  Returns float32[340]."""
     w0 = _np64(conv0_w).reshape(16, -1)
     G = w0.shape[1]
     assert G in (4, 8), f"unsupported group count {G}"
@@ -35,12 +35,16 @@ def pack_mlp(conv0_w, bn0, conv1_w, bn1, last_w, last_b, eps: float = BN_EPS) ->
     s0 = g0 / np.sqrt(v0 + eps)
     s1 = g1 / np.sqrt(v1 + eps)
     blk = np.zeros(MLP_FLOATS, np.float64)
-    blk[0:16 * G] = (w0 * s0[:, None]).reshape(-1)
-    blk[128:144] = b0 - m0 * s0
-    blk[144:272] = (w1 * s1[:, None]).reshape(-1)
-    blk[272:280] = b1 - m1 * s1
-    blk[280:288] = w2
-    blk[288] = b2
+    w0f = w0 * s0[:, None]          # [16, G]
+    w1f = w1 * s1[:, None]          # [8, 16]
+    t0 = b0 - m0 * s0
+    for j in range(16):
+        blk[20 * j:20 * j + G] = w0f[j]
+        blk[20 * j + 8:20 * j + 16] = w1f[:, j]
+        blk[20 * j + 16] = t0[j]
+    blk[320:328] = b1 - m1 * s1
+    blk[328:336] = w2
+    blk[336] = b2
     return np.ascontiguousarray(blk.astype(np.float32))
 
 

@@ -37,6 +37,7 @@ class _PointwiseMLP(nn.Module):
         self.conv1 = ConvBnReLU3D(in_channels=16, out_channels=8, kernel_size=1, stride=1, pad=0)
         self._packed: Optional[np.ndarray] = None
         self._packed_key = None
+        self._packed_dev: Optional[torch.Tensor] = None
 
     def _sources(self) -> List[torch.Tensor]:
         last = getattr(self, self._last)
@@ -44,14 +45,23 @@ class _PointwiseMLP(nn.Module):
                 last.weight, last.bias]
 
     def packed(self) -> np.ndarray:
-        """BN-folded float32[289] block for the kernel-argument segment (cached until a parameter changes)."""
+        """BN-folded float32[340] block for the kernel-argument segment (cached until a parameter changes)."""
         key = params.versions(self._sources())
         if self._packed is None or key != self._packed_key:
             last = getattr(self, self._last)
             self._packed = params.pack_mlp(self.conv0.conv.weight, self.conv0.bn_tensors(), self.conv1.conv.weight,
                                            self.conv1.bn_tensors(), last.weight, last.bias)
             self._packed_key = key
+            self._packed_dev = None
         return self._packed
+
+    def packed_device(self) -> torch.Tensor:
+        """The packed block as a device tensor on the parameters' device (what the kernels read)."""
+        blk = self.packed()
+        dev = self.conv0.conv.weight.device
+        if self._packed_dev is None or self._packed_dev.device != dev:
+            self._packed_dev = torch.from_numpy(blk).to(dev)
+        return self._packed_dev
 
 
 class PixelwiseNet(_PointwiseMLP):
@@ -85,7 +95,7 @@ class FeatureWeightNet(_PointwiseMLP):
 
     def forward(self, ref_nhwc: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray) -> torch.Tensor:
         """ref_nhwc [B,h,w,C], eval_offsets [B,2K,h,w] (raw eval_conv output) -> weights [B,K,h,w]."""
-        return ops.feature_weight(ref_nhwc, eval_offsets, table, self.packed(), self.G)
+        return ops.feature_weight(ref_nhwc, eval_offsets, table, self.packed_device(), self.G)
 
 
 class DepthInitialization(nn.Module):
@@ -137,7 +147,7 @@ class Evaluation(nn.Module):
             raise AssertionError("Patchmatch Evaluation: Different number of images and view weights")
         cost, vw, argmax, sim = ops.warp_correlate(
             ref_nhwc, src_nhwc, rel_proj, depth_sample, view_weights if have_vw else None, vw_shift,
-            self.similarity_net.packed(), None if have_vw else self.pixel_wise_net.packed(), self.G,
+            self.similarity_net.packed_device(), None if have_vw else self.pixel_wise_net.packed_device(), self.G,
             want_similarity=debug is not None, want_argmax=debug is not None and not have_vw)
         score, depth = ops.aggregate_regress(cost, depth_sample, xnorm, feature_weight, eval_offsets, table,
                                              interval_scale, is_inverse)

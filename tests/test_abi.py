@@ -98,8 +98,9 @@ def test_mlp_packing_folds_batchnorm():
     G = 4
     x = np.random.default_rng(0).standard_normal((1, G, 50)).astype(np.float32)
     ref = O.pointwise_mlp(x, params, "patchmatch_1.evaluation.similarity_net", "similarity", sigmoid=False)[0]
-    w0, t0 = blk[:16 * G].reshape(16, G), blk[128:144]
-    w1, t1, w2, b2 = blk[144:272].reshape(8, 16), blk[272:280], blk[280:288], blk[288]
+    rec = blk[:320].reshape(16, 20)
+    w0, w1, t0 = rec[:, :G], rec[:, 8:16].T, rec[:, 16]
+    t1, w2, b2 = blk[320:328], blk[328:336], blk[336]
     h0 = np.maximum(w0 @ x[0].astype(np.float64) + t0[:, None], 0)
     h1 = np.maximum(w1 @ h0 + t1[:, None], 0)
     out = w2 @ h1 + b2
