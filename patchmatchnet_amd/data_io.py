@@ -1,0 +1,175 @@
+"""On-disk formats either side of the hot path: DTU-style camera / pair text files, images,
+and the two depth-map containers eval.py writes (PFM, COLMAP .bin).  Format contract = reference datasets/data_io.py
+(:88-137 cams & pairs, :165-223 .bin, :226-302 PFM); the code is vectorised numpy (the reference packs .bin through
+a Python list, one struct field per pixel) and needs no OpenCV.
+"""
+from __future__ import annotations
+
+import re
+from typing import List, Tuple
+
+import numpy as np
+from PIL import Image
+
+
+def resize_bilinear(image: np.ndarray, height: int, width: int) -> np.ndarray:
+    """Plain bilinear resize with half-pixel centres and no anti-aliasing (what cv2.INTER_LINEAR computes on float
+    images, reference data_io.py:26-29).  image [H,W] or [H,W,C] float32."""
+    H, W = image.shape[:2]
+    ys = (np.arange(height, dtype=np.float64) + 0.5) * (H / height) - 0.5
+    xs = (np.arange(width, dtype=np.float64) + 0.5) * (W / width) - 0.5
+    ys = np.clip(ys, 0, H - 1)
+    xs = np.clip(xs, 0, W - 1)
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    y1 = np.minimum(y0 + 1, H - 1)
+    x1 = np.minimum(x0 + 1, W - 1)
+    fy = (ys - y0).astype(np.float32)
+    fx = (xs - x0).astype(np.float32)
+    if image.ndim == 3:
+        fy = fy[:, None, None]
+        fx = fx[None, :, None]
+    else:
+        fy = fy[:, None]
+        fx = fx[None, :]
+    top = image[y0][:, x0] * (1 - fx) + image[y0][:, x1] * fx
+    bot = image[y1][:, x0] * (1 - fx) + image[y1][:, x1] * fx
+    return (top * (1 - fy) + bot * fy).astype(np.float32)
+
+
+def scale_to_max_dim(image: np.ndarray, max_dim: int) -> Tuple[np.ndarray, int, int]:
+    """Down-scale so that max(H,W) <= max_dim (no-op for max_dim <= 0 or when already small enough); returns the image
+    and the ORIGINAL height / width (reference data_io.py:13-31)."""
+    h0, w0 = image.shape[0], image.shape[1]
+    scale = max_dim / max(h0, w0)
+    if 0 < scale < 1:
+        image = resize_bilinear(image, int(scale * h0), int(scale * w0))
+    return image, h0, w0
+
+
+def read_image(filename: str, max_dim: int = -1) -> Tuple[np.ndarray, int, int]:
+    """RGB image as float32 in [0,1], optionally down-scaled (reference data_io.py:34-47)."""
+    arr = np.array(Image.open(filename), dtype=np.float32) / 255.0
+    return scale_to_max_dim(arr, max_dim)
+
+
+def save_image(filename: str, image: np.ndarray) -> None:
+    """bool masks -> 0/255, float images in [0,1] -> uint8, everything else cast (reference data_io.py:50-64)."""
+    if image.dtype == bool:
+        out = image.astype(np.uint8) * 255
+    elif image.dtype in (np.float32, np.float64):
+        out = (image * 255).astype(np.uint8)
+    else:
+        out = image.astype(np.uint8)
+    Image.fromarray(out).save(filename)
+
+
+def read_cam_file(filename: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """MVSNet camera text file: line 0 'extrinsic', lines 1-4 the 4x4 matrix, line 6 'intrinsic', lines 7-9 the 3x3
+    matrix, line 11 (optional) 'depth_min depth_max ...' (reference data_io.py:88-110)."""
+    with open(filename) as f:
+        lines = [ln.rstrip() for ln in f.readlines()]
+    extrinsics = np.array(" ".join(lines[1:5]).split(), dtype=np.float32).reshape(4, 4)
+    intrinsics = np.array(" ".join(lines[7:10]).split(), dtype=np.float32).reshape(3, 3)
+    depth_params = np.array(lines[11].split(), dtype=np.float32) if len(lines) >= 12 else np.empty(0)
+    return intrinsics, extrinsics, depth_params
+
+
+def read_pair_file(filename: str) -> List[Tuple[int, List[int]]]:
+    """pair.txt: number of viewpoints, then per viewpoint its id and 'n id score id score ...'; viewpoints without
+    source views are dropped (reference data_io.py:113-131)."""
+    pairs = []
+    with open(filename) as f:
+        n = int(f.readline())
+        for _ in range(n):
+            ref = int(f.readline().rstrip())
+            src = [int(x) for x in f.readline().rstrip().split()[1::2]]
+            if src:
+                pairs.append((ref, src))
+    return pairs
+
+
+# ---- PFM (reference data_io.py:226-302): 'Pf' / 'PF', 'W H', scale (negative = little endian), rows bottom-up ------
+
+def read_pfm(filename: str) -> Tuple[np.ndarray, float]:
+    with open(filename, "rb") as f:
+        header = f.readline().decode("utf-8").rstrip()
+        if header not in ("PF", "Pf"):
+            raise Exception("Not a PFM file.")
+        m = re.match(r"^(\d+)\s(\d+)\s$", f.readline().decode("utf-8"))
+        if not m:
+            raise Exception("Malformed PFM header.")
+        width, height = int(m.group(1)), int(m.group(2))
+        scale = float(f.readline().rstrip())
+        endian = "<" if scale < 0 else ">"
+        data = np.fromfile(f, endian + "f")
+    channels = 3 if header == "PF" else 1
+    return np.flipud(data.reshape(height, width, channels)), abs(scale)
+
+
+def save_pfm(filename: str, image: np.ndarray, scale: float = 1) -> None:
+    if image.dtype != np.float32:
+        raise Exception("Image dtype must be float32.")
+    if image.ndim == 3 and image.shape[2] == 3:
+        magic = b"PF\n"
+    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
+        magic = b"Pf\n"
+    else:
+        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+    rows = np.ascontiguousarray(np.flipud(image)).astype("<f4", copy=False)
+    with open(filename, "wb") as f:
+        f.write(magic)
+        f.write(f"{image.shape[1]} {image.shape[0]}\n".encode("utf-8"))
+        f.write(("%f\n" % -abs(scale)).encode("utf-8"))  # negative scale: little-endian payload
+        rows.tofile(f)
+
+
+# ---- COLMAP .bin (reference data_io.py:165-223): 'W&H&C&' then float32 in column-major (x fastest = Fortran) order ---
+
+def read_bin(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        head = b""
+        while head.count(b"&") < 3:
+            byte = f.read(1)
+            if not byte:
+                raise Exception("Malformed .bin header.")
+            head += byte
+        width, height, channels = (int(x) for x in head.split(b"&")[:3])
+        data = np.fromfile(f, np.float32)
+    return np.transpose(data.reshape((width, height, channels), order="F"), (1, 0, 2))
+
+
+def save_bin(filename: str, data: np.ndarray) -> None:
+    if data.dtype != np.float32:
+        raise Exception("Image data type must be float32.")
+    if data.ndim == 2:
+        height, width = data.shape
+        channels = 1
+        payload = np.transpose(data, (1, 0))
+    elif data.ndim == 3 and data.shape[2] in (1, 3):
+        height, width, channels = data.shape
+        payload = np.transpose(data, (1, 0, 2))
+    else:
+        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+    with open(filename, "wb") as f:
+        f.write(f"{width}&{height}&{channels}&".encode("ascii"))
+        payload.reshape(-1, order="F").astype("<f4").tofile(f)
+
+
+def read_map(path: str, max_dim: int = -1) -> np.ndarray:
+    if path.endswith(".bin"):
+        data = read_bin(path)
+    elif path.endswith(".pfm"):
+        data, _ = read_pfm(path)
+    else:
+        raise Exception("Invalid input format; only pfm and bin are supported")
+    return scale_to_max_dim(data, max_dim)[0]
+
+
+def save_map(path: str, data: np.ndarray) -> None:
+    if path.endswith(".bin"):
+        save_bin(path, data)
+    elif path.endswith(".pfm"):
+        save_pfm(path, data)
+    else:
+        raise Exception("Invalid input format; only pfm and bin are supported")

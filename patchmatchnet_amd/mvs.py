@@ -1,0 +1,67 @@
+"""Sample source for eval.py: the generic MVS folder layout of the reference (datasets/mvs.py:8-111), inference only.
+
+    <data_path>/<scan>/images/[light/]00000000.jpg, <scan>/cams/00000000_cam.txt, <scan>/pair.txt
+
+One sample = one reference view + its first ``num_views`` source views.  ``shard(rank, world)`` hands every rank of a
+one-process-per-GPU job its slice of the reference views; no state is shared between samples.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+from torch.utils.data import Dataset
+
+from .data_io import read_cam_file, read_image, read_pair_file
+
+
+class MVSDataset(Dataset):
+    def __init__(self, data_path: str, num_views: int = 10, max_dim: int = -1, scan_list: str = "",
+                 num_light_idx: int = -1, cam_folder: str = "cams", pair_path: str = "pair.txt",
+                 image_folder: str = "images", image_extension: str = ".jpg") -> None:
+        super().__init__()
+        self.data_path, self.num_views, self.max_dim = data_path, num_views, max_dim
+        self.cam_folder, self.image_folder, self.image_extension = cam_folder, image_folder, image_extension
+        if os.path.isfile(scan_list):
+            with open(scan_list) as f:
+                scans = [ln.rstrip() for ln in f.readlines()]
+        else:
+            scans = [""]
+        lights = [str(i) for i in range(num_light_idx)] if num_light_idx > 0 else [""]
+        self.metas: List[Tuple[str, str, int, List[int]]] = []
+        for scan in scans:
+            pairs = read_pair_file(os.path.join(data_path, scan, pair_path))
+            for light in lights:
+                self.metas += [(scan, light, ref, src) for ref, src in pairs]
+
+    def shard(self, rank: int, world_size: int) -> "MVSDataset":
+        """Round-robin slice of the reference views for one rank (every rank keeps the full model replica)."""
+        if not 0 <= rank < world_size:
+            raise ValueError("rank out of range")
+        self.metas = self.metas[rank::world_size]
+        return self
+
+    def __len__(self) -> int:
+        return len(self.metas)
+
+    def __getitem__(self, idx: int) -> Dict:
+        scan, light, ref_view, src_views = self.metas[idx]
+        view_ids = [ref_view] + src_views[:min(len(src_views), self.num_views)]
+        images, intrinsics, extrinsics = [], [], []
+        depth_min = depth_max = -1.0
+        for i, vid in enumerate(view_ids):
+            img, h0, w0 = read_image(os.path.join(self.data_path, scan, self.image_folder, light,
+                                                  "{:0>8}{}".format(vid, self.image_extension)), self.max_dim)
+            images.append(np.ascontiguousarray(img.transpose(2, 0, 1)))
+            K, E, depth_params = read_cam_file(os.path.join(self.data_path, scan, self.cam_folder,
+                                                            "{:0>8}_cam.txt".format(vid)))
+            K[0] *= img.shape[1] / w0
+            K[1] *= img.shape[0] / h0
+            intrinsics.append(K)
+            extrinsics.append(E)
+            if i == 0:
+                depth_min, depth_max = depth_params[0], depth_params[1]
+        return {"images": images, "intrinsics": np.stack(intrinsics), "extrinsics": np.stack(extrinsics),
+                "depth_min": depth_min, "depth_max": depth_max, "ref_view": view_ids[0],
+                "filename": os.path.join(scan, "{}", "{:0>8}".format(view_ids[0]) + "{}")}

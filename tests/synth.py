@@ -61,3 +61,31 @@ def stage_projections(intr: np.ndarray, extr: np.ndarray, scale: float) -> np.nd
     proj = extr.astype(np.float32).copy()
     proj[:, :, :3, :4] = np.matmul(K, extr[:, :, :3, :4].astype(np.float32))
     return proj
+
+
+def write_scan(root: str, scan: str, n_views: int, H: int, W: int, n_src: int = 2) -> str:
+    """Writes a DTU-layout scan (images/*.jpg, cams/*_cam.txt, pair.txt) with the synthetic cameras above."""
+    import os
+    from PIL import Image
+    d = os.path.join(root, scan)
+    os.makedirs(os.path.join(d, "images"), exist_ok=True)
+    os.makedirs(os.path.join(d, "cams"), exist_ok=True)
+    intr, extr = synthetic_cameras(n_views, H, W)
+    imgs = synthetic_images(n_views, H, W)
+    for v in range(n_views):
+        arr = (imgs[v][0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+        Image.fromarray(arr).save(os.path.join(d, "images", "{:0>8}.jpg".format(v)), quality=95)
+        with open(os.path.join(d, "cams", "{:0>8}_cam.txt".format(v)), "w") as f:
+            f.write("extrinsic\n")
+            for r in extr[0, v]:
+                f.write(" ".join("%.8f" % x for x in r) + "\n")
+            f.write("\nintrinsic\n")
+            for r in intr[0, v]:
+                f.write(" ".join("%.8f" % x for x in r) + "\n")
+            f.write("\n425.0 935.0\n")
+    with open(os.path.join(d, "pair.txt"), "w") as f:
+        f.write("%d\n" % n_views)
+        for v in range(n_views):
+            others = [u for u in range(n_views) if u != v][:max(n_src, 1)]
+            f.write("%d\n%d " % (v, len(others)) + " ".join("%d %.2f" % (u, 100.0 - u) for u in others) + "\n")
+    return d

@@ -1,0 +1,158 @@
+"""CPU tests of the callers either side of the hot path: on-disk formats, the sample source, rank sharding, the per-scan
+all-gather (world_size 2 over gloo) and the consistency-fusion arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from patchmatchnet_amd import data_io, fusion
+from patchmatchnet_amd import dist as pdist
+from patchmatchnet_amd.mvs import MVSDataset
+
+
+def test_pfm_roundtrip_and_layout(tmp_path):
+    a = np.random.default_rng(0).standard_normal((7, 5)).astype(np.float32)
+    p = str(tmp_path / "a.pfm")
+    data_io.save_map(p, a)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"Pf\n5 7\n-1.000000\n")  # header bytes of the reference writer (data_io.py:289-300)
+    payload = np.frombuffer(raw[len(b"Pf\n5 7\n-1.000000\n"):], "<f4").reshape(7, 5)
+    np.testing.assert_array_equal(payload, a[::-1])  # rows stored bottom-up
+    b = data_io.read_map(p)
+    assert b.shape == (7, 5, 1)
+    np.testing.assert_array_equal(b[..., 0], a)
+    c = np.random.default_rng(1).random((4, 6, 3)).astype(np.float32)
+    data_io.save_pfm(str(tmp_path / "c.pfm"), c)
+    np.testing.assert_array_equal(data_io.read_pfm(str(tmp_path / "c.pfm"))[0], c)
+    with pytest.raises(Exception):
+        data_io.save_pfm(str(tmp_path / "d.pfm"), a.astype(np.float64))
+
+
+def test_colmap_bin_roundtrip_and_layout(tmp_path):
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    p = str(tmp_path / "a.bin")
+    data_io.save_map(p, a)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"4&3&1&")
+    # reference save_bin (data_io.py:209-217): transpose to (W,H), flatten in Fortran order => row-major x-fastest
+    np.testing.assert_array_equal(np.frombuffer(raw[6:], "<f4"), np.transpose(a, (1, 0)).reshape(-1, order="F"))
+    b = data_io.read_map(p)
+    assert b.shape == (3, 4, 1)
+    np.testing.assert_array_equal(b[..., 0], a)
+    with pytest.raises(Exception):
+        data_io.read_map(str(tmp_path / "x.png"))
+
+
+def test_resize_matches_plain_bilinear():
+    img = np.random.default_rng(2).random((40, 64, 3)).astype(np.float32)
+    out, h0, w0 = data_io.scale_to_max_dim(img, 32)
+    assert (h0, w0) == (40, 64) and out.shape == (20, 32, 3)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(20, 32), mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(out - ref).max() < 1e-6
+    same, _, _ = data_io.scale_to_max_dim(img, 128)
+    assert same is img
+    same, _, _ = data_io.scale_to_max_dim(img, -1)
+    assert same is img
+
+
+def test_scan_reader_and_sharding(tmp_path):
+    synth.write_scan(str(tmp_path), "scan1", n_views=5, H=64, W=96, n_src=3)
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("scan1\n")
+    ds = MVSDataset(str(tmp_path), num_views=2, max_dim=-1, scan_list=str(tmp_path / "list.txt"))
+    assert len(ds) == 5
+    s = ds[1]
+    assert len(s["images"]) == 3 and s["images"][0].shape == (3, 64, 96)
+    assert s["intrinsics"].shape == (3, 3, 3) and s["extrinsics"].shape == (3, 4, 4)
+    assert float(s["depth_min"]) == 425.0 and float(s["depth_max"]) == 935.0
+    assert s["filename"].format("depth_est", ".pfm") == os.path.join("scan1", "depth_est", "00000001.pfm")
+    intr, extr = synth.synthetic_cameras(5, 64, 96)
+    np.testing.assert_allclose(s["intrinsics"][0], intr[0, 1], rtol=1e-6)
+    np.testing.assert_allclose(s["extrinsics"][0], extr[0, 1], atol=1e-5)
+    # down-scaling rescales the intrinsics rows (reference mvs.py:86-87)
+    ds2 = MVSDataset(str(tmp_path), num_views=2, max_dim=48, scan_list=str(tmp_path / "list.txt"))
+    s2 = ds2[0]
+    assert s2["images"][0].shape == (3, 32, 48)
+    np.testing.assert_allclose(s2["intrinsics"][0][0], intr[0, 0][0] * 0.5, rtol=1e-6)
+    # rank sharding partitions the reference views
+    seen = []
+    for r in range(3):
+        d = MVSDataset(str(tmp_path), num_views=2, scan_list=str(tmp_path / "list.txt")).shard(r, 3)
+        seen += [m[2] for m in d.metas]
+    assert sorted(seen) == [0, 1, 2, 3, 4]
+    assert pdist.shard_views([0, 1, 2, 3, 4], 1, 3) == [1, 4]
+
+
+def _gather_worker(rank, world, port, H, W, ids, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, device = pdist.init_from_env("cpu")
+    assert (r, w) == (rank, world)
+    local = {vid: torch.full((2, H, W), float(vid)) + torch.arange(W).float() for vid in pdist.shard_views(ids, r, w)}
+    out = pdist.gather_scan_maps(local, ids, H, W, device)
+    ok = sorted(out) == sorted(ids) and all(
+        torch.equal(out[v], torch.full((2, H, W), float(v)) + torch.arange(W).float()) for v in ids)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scan_all_gather_world2_gloo():
+    """The N>1 path: 2 ranks, 5 views (ragged: 3 + 2, one padding slot) gathered with one all_gather_into_tensor."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, 6, 8, [3, 7, 11, 20, 42], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gather_single_process_is_identity():
+    local = {5: torch.rand(2, 4, 4), 9: torch.rand(2, 4, 4)}
+    out = pdist.gather_scan_maps(local, [5, 9], 4, 4, torch.device("cpu"))
+    assert torch.equal(out[5], local[5]) and torch.equal(out[9], local[9])
+
+
+def test_fusion_on_a_fronto_parallel_plane(tmp_path):
+    """Two cameras looking at the plane z = 600 (in camera-0 frame): exact depth maps must be mutually consistent, a
+    corrupted one must not; fused points lie on the plane."""
+    H, W = 48, 64
+    f = 80.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+    E0 = np.eye(4, dtype=np.float32)
+    E1 = np.eye(4, dtype=np.float32)
+    E1[0, 3] = -30.0  # camera 1 shifted along x; same orientation => depth of the plane is 600 in both
+    depth = np.full((H, W), 600.0, np.float32)
+    conf = np.full((H, W), 0.9, np.float32)
+    img = np.random.default_rng(0).random((H, W, 3)).astype(np.float32)
+    views = {0: dict(depth=depth, confidence=conf, intrinsics=K, extrinsics=E0, image=img),
+             1: dict(depth=depth.copy(), confidence=conf, intrinsics=K, extrinsics=E1, image=img)}
+    pairs = [(0, [1]), (1, [0])]
+    v, c, masks = fusion.fuse_scan(views, pairs, 1.0, 0.01, 1, 0.5, torch.device("cpu"))
+    photo, geo, final = masks[0]
+    assert photo.all()
+    # pixels whose projection falls inside the other image are consistent
+    shift = f * 30.0 / 600.0  # 4 px disparity towards -x in view 1 (+x in view 0)
+    inside = np.zeros((H, W), bool)
+    inside[:-1, int(np.ceil(shift)) + 1: W - int(np.ceil(shift)) - 1] = True
+    assert geo[inside].all() and final[inside].all()
+    np.testing.assert_allclose(v[:, 2][: int(final.sum())], 600.0, rtol=1e-5)
+    assert c.dtype == np.uint8 and c.shape[1] == 3
+    views[1]["depth"] = depth * 1.2  # inconsistent source depth => no geometric support
+    _, _, masks2 = fusion.fuse_scan(views, [(0, [1])], 1.0, 0.01, 1, 0.5, torch.device("cpu"))
+    assert not masks2[0][1].any()
+    ply = str(tmp_path / "o" / "fused.ply")
+    fusion.write_ply(ply, v, c)
+    head = open(ply, "rb").read(200).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(v))
+    assert os.path.getsize(ply) == len(open(ply, "rb").read().split(b"end_header\n")[0]) + len(b"end_header\n") + 15 * len(v)
