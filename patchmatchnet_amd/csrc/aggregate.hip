@@ -2,8 +2,8 @@
 // Reference: models/patchmatch.py:650-669 (depth_weight), :509-510 (weight normalisation), :569-577 (SimilarityNet
 // neighbour gather + weighted sum), :221 (exp(log_softmax)), :226-237 (regression).
 //
-// One thread per pixel.  The K neighbour tap sets (offset + 4 corner weights) and the K feature weights are computed
-// once and kept in registers; for every hypothesis d the thread gathers the neighbour's normalised inverse depth and
+// A thread owns a pixel and a strided subset of its hypotheses.  The K neighbour tap sets (offset + 4 corner weights) and
+// the K feature weights are computed once and kept in registers; for every hypothesis d the thread gathers the neighbour's normalised inverse depth and
 // pointwise cost at the same taps (both planes are [D,h,w], x fastest, so a wave's taps of one corner are a nearly
 // contiguous run), forms the depth weight, normalises over the K neighbours and accumulates the aggregated score.
 // The D scores are parked in the output score buffer (each thread re-reads only its own column) for the softmax and
@@ -25,13 +25,21 @@ struct AggArgs {
     int table[2 * PMN_MAX_NEIGHBORS];
 };
 
-template <int KMAX>
-__global__ __launch_bounds__(PMN_BLOCK) void aggregate_regress_kernel(const AggArgs a) {
+// Workgroup = NPX pixels x DL "hypothesis lanes" (NPX*DL = 256, pixel fastest so plane accesses stay coalesced):
+// thread (pixel, dl) handles hypotheses dl, dl+DL, ...; max / sum / regression partials are combined through LDS.
+// DL = 16 when D >= 32 (stage 3 has only 30k pixels at 1600x1200: one thread per pixel would leave most SIMDs idle).
+template <int KMAX, int DL>
+__global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regress_kernel(const AggArgs a) {
 #pragma clang fp contract(off)
+    constexpr int NPX = PMN_BLOCK / DL;
+    __shared__ float red[DL][NPX];
+    __shared__ float red2[DL][NPX];
     const int h = a.h, w = a.w, hw = h * w, D = a.D, K = a.K;
-    const int p = blockIdx.x * PMN_BLOCK + threadIdx.x;
+    const int px = threadIdx.x % NPX, dl = threadIdx.x / NPX;
+    const int p_raw = blockIdx.x * NPX + px;
+    const bool ok = p_raw < hw;
+    const int p = ok ? p_raw : hw - 1;  // out-of-range threads shadow the last pixel (no stores) so barriers stay uniform
     const int b = blockIdx.y;
-    if (p >= hw) return;
     const int y = p / w, x = p - y * w;
 
     int off[KMAX];
@@ -55,11 +63,10 @@ __global__ __launch_bounds__(PMN_BLOCK) void aggregate_regress_kernel(const AggA
         }
     }
 
-    // pass 1: aggregated score per hypothesis; parked in the (caller-owned) score buffer, which this thread alone
-    // reads back below -- keeps the hypothesis loop rolled (small code, few registers) for any D <= 64.
+    // pass 1: aggregated score of my hypotheses; parked in the (caller-owned) score buffer, re-read by this thread only
     float smax = -__builtin_inff();
 #pragma unroll 1
-    for (int d = 0; d < D; ++d) {
+    for (int d = dl; d < D; d += DL) {
         const float* xp = a.xnorm + ((size_t)b * D + d) * hw;
         const float* cp = a.cost + ((size_t)b * D + d) * hw;
         const float xc = xp[p];
@@ -84,43 +91,68 @@ __global__ __launch_bounds__(PMN_BLOCK) void aggregate_regress_kernel(const AggA
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K) s = s + ck[k] * (wk[k] / wsum);
-        a.score[((size_t)b * D + d) * hw + p] = s;
+        if (ok) a.score[((size_t)b * D + d) * hw + p] = s;
         smax = fmaxf(smax, s);
     }
+    red[dl][px] = smax;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DL; ++i) smax = fmaxf(smax, red[i][px]);
+    __syncthreads();
 
-    // pass 2/3: exp(log_softmax(score)) over the hypotheses, then the regression
+    // pass 2: exp(log_softmax): log of the sum of exponentials over all hypotheses of the pixel
     float esum = 0.0f;
 #pragma unroll 1
-    for (int d = 0; d < D; ++d) esum = esum + expf(a.score[((size_t)b * D + d) * hw + p] - smax);
+    for (int d = dl; d < D; d += DL)
+        if (ok) esum = esum + expf(a.score[((size_t)b * D + d) * hw + p] - smax);
+    red[dl][px] = esum;
+    __syncthreads();
+    esum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DL; ++i) esum = esum + red[i][px];
     const float lse = logf(esum);
+
+    // pass 3: probabilities + regression partial sums
     float acc = 0.0f;
-    float d_first = 0.0f, d_last = 0.0f;
 #pragma unroll 1
-    for (int d = 0; d < D; ++d) {
-        const size_t o = ((size_t)b * D + d) * hw + p;
-        const float prob = expf((a.score[o] - smax) - lse);
-        a.score[o] = prob;
-        const float ds = a.depth[o];
-        if (d == 0) d_first = ds;
-        if (d == D - 1) d_last = ds;
-        acc = acc + (a.is_inverse ? (float)d : ds) * prob;
+    for (int d = dl; d < D; d += DL) {
+        if (ok) {
+            const size_t o = ((size_t)b * D + d) * hw + p;
+            const float prob = expf((a.score[o] - smax) - lse);
+            a.score[o] = prob;
+            acc = acc + (a.is_inverse ? (float)d : a.depth[o]) * prob;
+        }
     }
+    red2[dl][px] = acc;
+    __syncthreads();
+    if (dl != 0 || !ok) return;
+    acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DL; ++i) acc = acc + red2[i][px];
     float out = acc;
     if (a.is_inverse) {
-        const float inv_min = 1.0f / d_last;
-        const float inv_max = 1.0f / d_first;
+        const float inv_min = 1.0f / a.depth[((size_t)b * D + (D - 1)) * hw + p];
+        const float inv_max = 1.0f / a.depth[((size_t)b * D) * hw + p];
         const float inv = inv_max + acc / (float)(D - 1) * (inv_min - inv_max);
         out = 1.0f / inv;
     }
     a.depth_out[(size_t)b * hw + p] = out;
 }
 
-template <int KMAX>
-static int launch_agg(const AggArgs& a, hipStream_t s) {
-    const dim3 grid((a.h * a.w + PMN_BLOCK - 1) / PMN_BLOCK, a.B), block(PMN_BLOCK);
-    hipLaunchKernelGGL((aggregate_regress_kernel<KMAX>), grid, block, 0, s, a);
+template <int KMAX, int DL>
+static int launch_agg_dl(const AggArgs& a, hipStream_t s) {
+    constexpr int NPX = PMN_BLOCK / DL;
+    const dim3 grid((a.h * a.w + NPX - 1) / NPX, a.B), block(PMN_BLOCK);
+    hipLaunchKernelGGL((aggregate_regress_kernel<KMAX, DL>), grid, block, 0, s, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
+}
+
+template <int KMAX>
+static int launch_agg(const AggArgs& a, hipStream_t s) {
+    if (a.D >= 32) return launch_agg_dl<KMAX, 16>(a, s);
+    if (a.D >= 16) return launch_agg_dl<KMAX, 4>(a, s);
+    return launch_agg_dl<KMAX, 1>(a, s);  // stage 1: 480k pixels already fill the chip (measured: DL=4 is slower)
 }
 
 extern "C" int pmn_aggregate_regress(const float* cost, const float* depth_sample, const float* xnorm,

@@ -105,11 +105,15 @@ class PatchmatchNet(nn.Module):
             state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def extract_features(self, images: List[torch.Tensor]) -> List[Dict[int, torch.Tensor]]:
+    def extract_features(self, images: List[torch.Tensor], stacked: Optional[dict] = None) -> List[Dict[int, torch.Tensor]]:
+        """Per-view feature pyramids.  ``stacked`` (a dict) additionally receives {stage: [V*B,C,h,w]} when all views
+        went through FeatureNet as one batch (view-major), so the caller can change layout in one pass."""
         same = all(im.shape == images[0].shape for im in images)
         if self.batch_feature_extraction and same and len(images) > 1:
             B = images[0].shape[0]
             f = self.feature(torch.cat(images, dim=0))
+            if stacked is not None:
+                stacked.update(f)
             return [{s: t[i * B:(i + 1) * B] for s, t in f.items()} for i in range(len(images))]
         return [self.feature(im) for im in images]
 
@@ -131,9 +135,11 @@ class PatchmatchNet(nn.Module):
         ref_image = images[0]
         _, _, ref_height, ref_width = ref_image.size()
 
+        stacked: Dict[int, torch.Tensor] = {}
         if features is None:
-            features = self.extract_features(images)
+            features = self.extract_features(images, stacked)
         ref_feature, src_features = features[0], features[1:]
+        batch = ref_image.shape[0]
 
         depth_min = depth_min.float()
         depth_max = depth_max.float()
@@ -157,11 +163,16 @@ class PatchmatchNet(nn.Module):
 
             dbg = [] if debug is not None else None
             pm: PatchMatch = getattr(self, f"patchmatch_{stage}")
+            ref_nhwc = src_nhwc = None
+            if stage in stacked:  # one layout pass for all views of the stage
+                allv = ops.nchw_to_nhwc(stacked[stage].contiguous())
+                ref_nhwc = allv[:batch]
+                src_nhwc = allv[batch:].view(len(src_features), batch, *allv.shape[1:])
             depths, score, view_weights = pm(
                 ref_feature=ref_feature[stage], src_features=[f[stage] for f in src_features], ref_proj=ref_proj,
                 src_projs=list(src_proj), depth_min=depth_min, depth_max=depth_max, depth=depth,
                 view_weights=view_weights, depth_shift=depth_shift, vw_shift=vw_shift,
-                noise=noise if stage == self.stages - 1 else None, debug=dbg)
+                noise=noise if stage == self.stages - 1 else None, debug=dbg, ref_nhwc=ref_nhwc, src_nhwc=src_nhwc)
             if debug is not None:
                 debug[stage] = dbg
             depth_patchmatch[stage] = depths

@@ -194,11 +194,13 @@ class PatchMatch(nn.Module):
     def forward(self, ref_feature: torch.Tensor, src_features: List[torch.Tensor], ref_proj: torch.Tensor,
                 src_projs: List[torch.Tensor], depth_min: torch.Tensor, depth_max: torch.Tensor, depth: torch.Tensor,
                 view_weights: torch.Tensor, depth_shift: int = 0, vw_shift: int = 0, noise: Optional[torch.Tensor] = None,
-                debug: Optional[list] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+                debug: Optional[list] = None, ref_nhwc: Optional[torch.Tensor] = None,
+                src_nhwc: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
         """Reference arguments, plus optional extras that default to reference behaviour:
         ``depth_shift`` / ``vw_shift`` = 1 read ``depth`` / ``view_weights`` given at half resolution through the
         nearest x2 up-sampling (skips materialising F.interpolate); ``noise`` pins the stage-3 random draw;
-        ``debug`` (a list) receives one dict of intermediates per iteration."""
+        ``debug`` (a list) receives one dict of intermediates per iteration; ``ref_nhwc`` [B,h,w,C] / ``src_nhwc``
+        [N,B,h,w,C] hand over channels-last copies the caller already made (one layout pass for all views)."""
         if len(src_features) != len(src_projs):
             raise AssertionError("Patchmatch Evaluation: Different number of images and projection matrices")
         if not ref_feature.is_cuda:
@@ -211,8 +213,10 @@ class PatchMatch(nn.Module):
         propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None
         eval_offsets = self.eval_conv(ref_feature).contiguous()
 
-        ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
-        src_nhwc = ops.stack_sources_nhwc([f.detach().contiguous() for f in src_features])
+        if ref_nhwc is None:
+            ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
+        if src_nhwc is None:
+            src_nhwc = ops.stack_sources_nhwc([f.detach().contiguous() for f in src_features])
         rel_proj = ops.relative_projection(src_projs, ref_proj)
         depth_min = depth_min.float().contiguous()
         depth_max = depth_max.float().contiguous()
