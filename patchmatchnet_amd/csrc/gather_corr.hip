@@ -47,7 +47,7 @@ struct GatherArgs {
     int* vw_argmax;        // [B,N,h,w] or null
     float* sim_out;        // [B,G,D,h,w] or null
     float* out;            // [B,D,h,w]
-    int B, N, D, h, w, hs, ws, vw_shift, vchunk, ntiles;
+    int B, N, D, h, w, hs, ws, vw_shift, ntiles;
     int table[2 * PMN_MAX_NEIGHBORS];
 };
 
@@ -135,8 +135,27 @@ __device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
     return acc + a * b;  // two roundings, like the reference's separate mul and add kernels
 }
 
+// Broadcast `v` from lane SL of every aligned group of LPI lanes (SL compile-time): DPP quad_perm for 4-lane groups,
+// DPP row_newbcast for 16-lane groups (one VALU op, no LDS), ds_bpermute for 8-lane groups.
+template <int LPI, int SL>
+__device__ __forceinline__ int group_bcast_i(int v) {
+    if constexpr (LPI == 4) {
+        return __builtin_amdgcn_update_dpp(0, v, SL | (SL << 2) | (SL << 4) | (SL << 6), 0xF, 0xF, false);
+    } else if constexpr (LPI == 16) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x150 + SL, 0xF, 0xF, false);
+    } else {
+        return __shfl(v, (int)((threadIdx.x & 63u) & ~(unsigned)(LPI - 1)) + SL, 64);
+    }
+}
+template <int LPI, int SL>
+__device__ __forceinline__ float group_bcast_f(float v) {
+    return __int_as_float(group_bcast_i<LPI, SL>(__float_as_int(v)));
+}
+
 // One (pixel, hypothesis) item of the lane role: returns this lane's group-correlation value (valid in the owner lane
 // of each group; with 8-channel groups both lanes of the pair hold it).
+typedef float pmn_f2 __attribute__((ext_vector_type(2)));
+
 template <int LPI, int LPG, int CG>
 __device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, const float4 w4, const int off, const int ws,
                                              const float4 refq) {
@@ -145,19 +164,26 @@ __device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, co
     const float4 t01 = bp[LPI];
     const float4 t10 = bp[(size_t)ws * LPI];
     const float4 t11 = bp[(size_t)ws * LPI + LPI];
-    float4 val;
-    val.x = fmaf(t11.x, w4.w, fmaf(t10.x, w4.z, fmaf(t01.x, w4.y, t00.x * w4.x)));
-    val.y = fmaf(t11.y, w4.w, fmaf(t10.y, w4.z, fmaf(t01.y, w4.y, t00.y * w4.x)));
-    val.z = fmaf(t11.z, w4.w, fmaf(t10.z, w4.z, fmaf(t01.z, w4.y, t00.z * w4.x)));
-    val.w = fmaf(t11.w, w4.w, fmaf(t10.w, w4.z, fmaf(t01.w, w4.y, t00.w * w4.x)));
-    float s = fmaf(val.w, refq.w, fmaf(val.z, refq.z, fmaf(val.y, refq.y, val.x * refq.x)));
+    // packed fp32 math (v_pk_mul/v_pk_fma: two channels per instruction); per channel the order of operations is the
+    // same as the scalar form: ((t00*w00 + t01*w01) + t10*w10) + t11*w11, then the dot product with the reference quad
+    const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
+    pmn_f2 lo = pmn_f2{t00.x, t00.y} * wa;
+    pmn_f2 hi = pmn_f2{t00.z, t00.w} * wa;
+    lo = __builtin_elementwise_fma(pmn_f2{t01.x, t01.y}, wb, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{t01.z, t01.w}, wb, hi);
+    lo = __builtin_elementwise_fma(pmn_f2{t10.x, t10.y}, wc, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{t10.z, t10.w}, wc, hi);
+    lo = __builtin_elementwise_fma(pmn_f2{t11.x, t11.y}, wd, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{t11.z, t11.w}, wd, hi);
+    float s = fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
     if (LPG == 2) s += pmn_pair_swap(s);
     return s * (1.0f / CG);
 }
 
-// __launch_bounds__ second argument = minimum waves per SIMD: 4 (<= 128 VGPRs, 4 workgroups per CU) keeps enough
-// waves resident to cover the gather latency; the PixelwiseNet variant is LDS-limited to 3 workgroups per CU anyway.
-template <int C, int G, int MODE, int DT>
+// EXACT: the hypothesis count equals the compile-time bound DT, so every `d < D` test folds away and the unrolled phase-B
+// loop is straight-line code (with run-time guards each item becomes its own basic block and hipcc serialises
+// load -> wait -> compute per item: no memory-level parallelism).
+template <int C, int G, int MODE, int DT, bool EXACT>
 __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void gather_corr_kernel(const GatherArgs a) {
     constexpr int LPI = C / 4;               // lanes per (pixel, hypothesis) item
     constexpr int NPIX = PMN_BLOCK / LPI;    // pixels per workgroup tile
@@ -175,13 +201,13 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int tile = pmn_xcd_tile(blockIdx.x, a.ntiles);
-    const int D = a.D, N = a.N, h = a.h, w = a.w, hs = a.hs, ws = a.ws;
+    const int D = EXACT ? DT : a.D;
+    const int N = a.N, h = a.h, w = a.w, hs = a.hs, ws = a.ws;
     const int hw = h * w;
     const int items = NPIX * D;
     const int SS = items + PAD;
     const int p0 = tile * NPIX;
-    const int vchunk = (MODE == MODE_VIEWS) ? a.vchunk : 1;
-    const int rcap = (MODE == MODE_VIEWS) ? vchunk * items : NPIX * min(D, DCH);
+    const int rcap = (MODE == MODE_VIEWS) ? 0 : NPIX * min(D, DCH);
 
     extern __shared__ float4 smem4[];
     float4* recw = smem4;                                         // [rcap] corner weights
@@ -222,8 +248,26 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
     const bool owner = (lc % LPG) == 0;
     const int gB = lc / LPG;
 
+    // Homography coefficients of this thread's pixel for one view: p(d) = r * d + t with r = R [x y 1]^T.  The source map
+    // scale (ws-1)/(w-1) of the reference's normalise -> un-normalise round trip (module.py:170-181) is folded in.
+    // Positions are computed with v_rcp + one Newton step instead of the reference's chain of IEEE divisions: they agree
+    // with the reference's fp32 positions to ~1e-4 px (both carry that much rounding noise at 800-px coordinates).
+    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
+    struct Pose { float rx, ry, rz, tx, ty, tz; };
+    auto make_pose = [&](const float* P) {
+        Pose q;
+        const float x = (float)xA, y = (float)yA;
+        q.rx = (fmaf(P[0], x, P[1] * y) + P[2]) * sxs;
+        q.ry = (fmaf(P[4], x, P[5] * y) + P[6]) * sys;
+        q.rz = fmaf(P[8], x, P[9] * y) + P[10];
+        q.tx = P[3] * sxs;
+        q.ty = P[7] * sys;
+        q.tz = P[11];
+        return q;
+    };
+
     // phase A for one view / hypothesis range [d_lo, d_hi): records land at rec_base + (d - d_lo)*NPIX + pixA
-    auto phase_a = [&](const float* P, int d_lo, int d_hi, int rec_base) {
+    auto phase_a = [&](const Pose& q, int d_lo, int d_hi, int rec_base) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int d = dA0 + j * DSTEP;
@@ -232,16 +276,21 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             t.off = 0;
             t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
             if (okA) {
-                float ix, iy;
                 if (MODE == MODE_NEIGHBOR) {
+                    float ix, iy;
                     const float ox = a.offsets[((size_t)b * 2 * D + 2 * d) * hw + pA];
                     const float oy = a.offsets[((size_t)b * 2 * D + 2 * d + 1) * hw + pA];
                     pmn_neighbor_position((float)xA, (float)yA, tab[2 * d], tab[2 * d + 1], ox, oy, h, w, ix, iy);
+                    t = pmn_make_taps(ix, iy, hs, ws);
                 } else {
                     const float dep = a.depth[((size_t)b * D + d) * hw + pA];
-                    pmn_warp_position(P, (float)xA, (float)yA, dep, h, w, hs, ws, ix, iy);
+                    const float pz = fmaf(q.rz, dep, q.tz);
+                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
+                        float inv = __builtin_amdgcn_rcpf(pz);
+                        inv = inv * fmaf(-pz, inv, 2.0f);
+                        t = pmn_make_taps(fmaf(q.rx, dep, q.tx) * inv, fmaf(q.ry, dep, q.ty) * inv, hs, ws);
+                    }
                 }
-                t = pmn_make_taps(ix, iy, hs, ws);
             }
             const int i = rec_base + (d - d_lo) * NPIX + pixA;
             recw[i] = make_float4(t.w00, t.w01, t.w10, t.w11);
@@ -250,32 +299,81 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
     };
 
     if (MODE == MODE_VIEWS) {
-        // ================= known view weights: accumulate over views in registers =======================================
+        // ================= known view weights: barrier-free streaming over the views ================================
+        // Each lane projects RPL = DT/LPI hypotheses of ITS OWN pixel (d = lc + j*LPI), keeps the tap records in
+        // registers and the records are broadcast inside the lane group when hypothesis d is gathered -- no LDS
+        // round trip and no workgroup barrier inside the view loop, so every wave streams on its own and the tap
+        // loads of one wave overlap the projection math of the others.  Sums over views accumulate in registers.
+        constexpr int RPL = DT / LPI;
+        static_assert(DT % LPI == 0, "DT is a multiple of the lane-group size");
         float acc[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) acc[d] = 0.0f;
-        for (int v0 = 0; v0 < N; v0 += vchunk) {
-            const int nv = min(vchunk, N - v0);
-            for (int vc = 0; vc < nv; ++vc) phase_a(a.proj + ((size_t)b * N + (v0 + vc)) * 16, 0, D, vc * items);
-            __syncthreads();
-            for (int vc = 0; vc < nv; ++vc) {
-                const int v = v0 + vc;
-                const float4* srcv = reinterpret_cast<const float4*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * LPI + lc;
-                const float vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
-                const float4* rw = recw + vc * items + grp;
-                const int* ro = reco + vc * items + grp;
+        const float xf = (float)xB, yf = (float)yB;
+        float rdep[RPL];  // my RPL hypotheses (the same for every view)
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    if (d < D) {
-                        const float s = gather_item<LPI, LPG, CG>(srcv, rw[d * NPIX], ro[d * NPIX], ws, refq);
-                        acc[d] = mul_add_unfused(acc[d], s, vw);
+        for (int j = 0; j < RPL; ++j) {
+            const int d = lc + j * LPI;
+            rdep[j] = (okB && d < D) ? a.depth[((size_t)b * D + d) * hw + pB] : -1.0f;
+        }
+        for (int v = 0; v < N; ++v) {
+            const float* P = a.proj + ((size_t)b * N + v) * 16;
+            const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx = P[3] * sxs;
+            const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty = P[7] * sys;
+            const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+            float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
+            int roff[RPL];
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int d = lc + j * LPI;
+                PmnTaps t;
+                t.off = 0;
+                t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+                if (okB && d < D) {
+                    const float dep = rdep[j];
+                    const float pz = fmaf(rz, dep, tz);
+                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
+                        float inv = __builtin_amdgcn_rcpf(pz);
+                        inv = inv * fmaf(-pz, inv, 2.0f);
+                        t = pmn_make_taps(fmaf(rx, dep, tx) * inv, fmaf(ry, dep, ty) * inv, hs, ws);
                     }
-                    // keep at most 4 items (16 x dwordx4) in flight: without the fence the scheduler hoists every load
-                    // of the unrolled loop and the register allocator spills
-                    if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+                rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
+                roff[j] = t.off;
             }
-            __syncthreads();
+            const float4* srcv = reinterpret_cast<const float4*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * LPI + lc;
+            const float vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                if (EXACT || d < D) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    float4 w4;
+                    int off;
+                    // compile-time (j, source lane) of hypothesis d
+#define PMN_BCAST_CASE(SL)                                                    \
+    case SL:                                                                  \
+        w4.x = group_bcast_f<LPI, SL>(rw00[d / LPI]);                         \
+        w4.y = group_bcast_f<LPI, SL>(rw01[d / LPI]);                         \
+        w4.z = group_bcast_f<LPI, SL>(rw10[d / LPI]);                         \
+        w4.w = group_bcast_f<LPI, SL>(rw11[d / LPI]);                         \
+        off = group_bcast_i<LPI, SL>(roff[d / LPI]);                          \
+        break;
+                    switch (d % LPI) {
+                        PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
+                        PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
+                        PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
+                        PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
+                        default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
+                    }
+#undef PMN_BCAST_CASE
+                    const float s = gather_item<LPI, LPG, CG>(srcv, w4, off, ws, refq);
+                    acc[d] = mul_add_unfused(acc[d], s, vw);
+                }
+                // keep at most 4 items (16 x dwordx4) in flight: without the fence the scheduler hoists every load
+                // of the unrolled loop and the register allocator spills
+                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (owner) {
 #pragma unroll
@@ -320,12 +418,13 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
 
     for (int v = 0; v < N; ++v) {
         if (MODE == MODE_PIXELWISE && tid < NPIX) vwkey[tid] = 0ull;
-        const float* P = a.proj + ((size_t)b * N + v) * 16;
+        Pose pose = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (MODE != MODE_NEIGHBOR) pose = make_pose(a.proj + ((size_t)b * N + v) * 16);
         const float4* srcv = reinterpret_cast<const float4*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
                              ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * LPI + lc;
         for (int dc0 = 0; dc0 < D; dc0 += DCH) {
             const int dc1 = min(D, dc0 + DCH);
-            phase_a(P, dc0, dc1, 0);
+            phase_a(pose, dc0, dc1, 0);
             __syncthreads();
             const float4* rw = recw + grp;
             const int* ro = reco + grp;
@@ -414,19 +513,17 @@ static int env_int(const char* name, int dflt) {
     return s ? atoi(s) : dflt;
 }
 
-template <int C, int G, int MODE, int DT>
-static int launch_gather(GatherArgs& a, hipStream_t stream) {
+template <int C, int G, int MODE, int DT, bool EXACT>
+static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     constexpr int LPI = C / 4, NPIX = PMN_BLOCK / LPI, PAD = 32 / G;
     const int hw = a.h * a.w;
     a.ntiles = (hw + NPIX - 1) / NPIX;
-    if (MODE != MODE_VIEWS) a.vchunk = 1;
-    a.vchunk = a.vchunk < 1 ? 1 : (a.vchunk > a.N ? a.N : a.vchunk);
     const int items = NPIX * a.D, SS = items + PAD;
-    const int rcap = (MODE == MODE_VIEWS) ? a.vchunk * items : NPIX * (a.D < 32 ? a.D : 32);
+    const int rcap = (MODE == MODE_VIEWS) ? 0 : NPIX * (a.D < 32 ? a.D : 32);
     size_t lds = (size_t)rcap * 20 + (size_t)((G * SS + 3) & ~3) * 4 + 2 * MLP_LDS_FLOATS * 4 + NPIX * 8 +
                  2 * PMN_MAX_NEIGHBORS * 4;
     lds = (lds + 15) & ~(size_t)15;
-    auto kern = gather_corr_kernel<C, G, MODE, DT>;
+    auto kern = gather_corr_kernel<C, G, MODE, DT, EXACT>;
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -436,6 +533,14 @@ static int launch_gather(GatherArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
+}
+
+template <int C, int G, int MODE, int DT>
+static int launch_gather(GatherArgs& a, hipStream_t stream) {
+    if constexpr (MODE == MODE_VIEWS) {
+        if (a.D == DT) return launch_gather_impl<C, G, MODE, DT, true>(a, stream);
+    }
+    return launch_gather_impl<C, G, MODE, DT, false>(a, stream);
 }
 
 // DT = compile-time bound of the hypothesis loop: next power of two >= D, and >= the item-role stride C/4
@@ -490,7 +595,6 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     a.out = cost_out;
     a.B = B; a.N = N; a.D = D; a.h = h; a.w = w; a.hs = hs; a.ws = ws;
     a.vw_shift = vw_shift;
-    a.vchunk = env_int("PMN_VCHUNK", 2);
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }
@@ -509,7 +613,6 @@ extern "C" int pmn_feature_weight(const float* ref_nhwc, const float* eval_offse
     a.mlp_a = mlp;
     a.out = out_feature_weight;
     a.B = B; a.N = 1; a.D = K; a.h = h; a.w = w; a.hs = h; a.ws = w;
-    a.vchunk = 1;
     for (int i = 0; i < 2 * K; ++i) a.table[i] = eval_table_host[i];
     return dispatch_gather<MODE_NEIGHBOR>(a, C, G, (hipStream_t)stream);
 }

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
+    ap.add_argument("--flat", action="store_true", help="all hypotheses of a pixel equal: ~100%% L1 hits (upper bound probe)")
     args = ap.parse_args()
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops, params
@@ -78,6 +79,8 @@ def main():
             band = {3: 0.025, 2: 0.0125, 1: 0.005}[stage] * (1 / 425.0 - 1 / 935.0)
             k = (torch.arange(D).float() - D // 2).view(1, D, 1, 1) * (8.0 / D if stage == 1 else 1.0)
             inv = (centre + band * k).clamp(1 / 935.0, 1 / 425.0)
+        if args.flat:
+            inv = inv[:, :1].expand(-1, D, -1, -1)
         hyp = (1.0 / inv).sort(dim=1)[0].contiguous().to(dev)
         vw = None if pixelwise else torch.rand(1, N, h, w, generator=gen).to(dev)
         sim_mlp = pm.evaluation.similarity_net.packed_device()
