@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 2
+#define PMN_ABI_VERSION 3
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -106,6 +106,25 @@ int pmn_aggregate_regress(const float *cost, const float *depth_sample, const fl
  * probabilities around trunc(sum_d d*p_d), nearest resize to [B,H,W].  depth_index_out (optional) [B,h,w]. */
 int pmn_confidence(const float *score, int B, int D, int h, int w, int H, int W, float *confidence_out,
                    int *depth_index_out, void *stream);
+
+/* Direct fp32 convolution with fused epilogue for the small-channel CNNs around the hot path: FeatureNet's ConvBnReLU
+ * stack and FPN head (reference models/net.py:17-67), the offset heads propa_conv / eval_conv
+ * (models/patchmatch.py:288-311, 467-471).  out = [relu]( conv(in, W) + shift [+ bilinear_x2(up)] ).
+ *   in       [N,H,W,cin] channels-last, or [N,cin,H,W] when in_nchw (cin = 3 or 1: the image / depth planes)
+ *   weights  DEVICE float [K][K][cin][coutp], coutp = cout rounded up to 8 (cout <= 8) or a multiple of 16, BatchNorm scale
+ *            folded in (patchmatchnet_amd/params.py: pack_conv); shift DEVICE float[coutp] (folded BN shift or conv bias)
+ *   up       optional [N,up_h,up_w,cout] map, bilinearly up-sampled x2 (align_corners=False) and added (net.py:60,65)
+ *   out      [N,Ho,Wo,cout] channels-last, or planar [N,cout,Ho,Wo] when out_nchw (the offset planes the PatchMatch
+ *            kernels read).  Supported (cin,K,stride): (3|1,3,1 nchw-in), (8|16|32|64,3,1), (8|16|32,5,2), (16|32|64,1,1). */
+int pmn_conv2d(const float *in, const float *weights, const float *shift, const float *up, float *out, int N, int H,
+               int W, int cin, int cout, int K, int stride, int pad, int dil, int relu, int in_nchw, int out_nchw,
+               int up_h, int up_w, void *stream);
+
+/* Fused tail of FeatureNet's FPN (reference models/net.py:64-67): out = output3( bilinear_x2(up) + inner2(x) ) without
+ * materialising the 64-channel half-resolution map.  x [N,H,W,16], up [N,H/2,W/2,64], w_in [16][64] / b_in [64] and
+ * w_out [64][16] in pack_conv layout (device) -> out [N,H,W,16]. */
+int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float *b_in, const float *w_out, float *out,
+                 int N, int H, int W, int cin, int cmid, int cout, void *stream);
 
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */

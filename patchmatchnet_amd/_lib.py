@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -36,6 +36,8 @@ SIGNATURES = {
                            _fp, _s],
     "pmn_aggregate_regress": [_fp, _fp, _fp, _fp, _fp, _hp, _i, _f, _i, _i, _i, _i, _i, _fp, _fp, _s],
     "pmn_confidence": [_fp, _i, _i, _i, _i, _i, _i, _fp, _ip, _s],
+    "pmn_conv2d": [_fp, _fp, _fp, _fp, _fp] + [_i] * 14 + [_s],
+    "pmn_fpn_tail": [_fp] * 6 + [_i] * 6 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
 }
 

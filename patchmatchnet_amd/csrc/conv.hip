@@ -1,0 +1,477 @@
+// conv.hip -- direct fp32 convolutions for the small-channel CNNs around the hot path: FeatureNet (reference
+// models/net.py:9-70), the offset heads propa_conv / eval_conv (models/patchmatch.py:288-311) and Refinement pieces.
+//
+// Why not MIOpen: at 3..64 channels MIOpen's fp32 Winograd kernels plus the separate BatchNorm, ReLU, add and
+// bilinear-upsample passes take 7.6 ms per 1600x1200 6-view sample (profiles/), 20 TFLOP/s effective.  Here one kernel
+// does conv + folded BatchNorm shift + ReLU (+ the FPN "upsample x2 and add" of net.py:60-66) and keeps every map
+// channels-last, which is also the layout the PatchMatch kernels want (no transposition pass).
+//
+// Mapping (wave64, 256 threads): a thread owns TP consecutive output pixels x COUT_T (8 or 16) output channels in
+// registers.  Loops over (ky, kx, 4-channel input chunk) are ROLLED; inside, the thread loads one float4 of input per
+// pixel (NHWC: 16 contiguous bytes) and issues 4*COUT_T*TP FMAs whose weight operands are wave-uniform, i.e. scalar
+// loads / SGPR operands ([K][K][CIN][COUTP] weight layout: the COUT_T weights of one input channel are contiguous).
+// fp32 throughout (fp16/bf16 features are not parity-safe); BatchNorm is folded into the weights in fp64.
+#include <cstring>
+
+#include "pmn_common.hpp"
+
+struct ConvArgs {
+    int N, H, W, Ho, Wo, COUTP, cout, pad, dil, relu, up_h, up_w;
+};
+
+// bilinear x2 up-sampling (align_corners=False) source taps of ATen's upsample_bilinear2d
+__device__ __forceinline__ void up2_taps(int o, int size_in, int& i0, int& i1, float& l1) {
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < size_in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+template <int CIN, int COUT_T, int K, int S, int TP, bool IN_NCHW, bool OUT_NCHW>
+__global__ __launch_bounds__(PMN_BLOCK) void conv_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                         const float* __restrict__ shift, const float* __restrict__ up,
+                                                         float* __restrict__ out, const ConvArgs a) {
+    constexpr int CSTEP = IN_NCHW ? 1 : 4;
+    static_assert(IN_NCHW || CIN % 4 == 0, "NHWC input needs a multiple of 4 channels");
+    const int wg = (a.Wo + TP - 1) / TP;
+    const int gid = blockIdx.x * PMN_BLOCK + threadIdx.x;
+    const int total = a.N * a.Ho * wg;
+    const bool live = gid < total;
+    const int g = live ? gid : total - 1;
+    const int ox0 = (g % wg) * TP;
+    const int oy = (g / wg) % a.Ho;
+    const int n = g / (wg * a.Ho);
+    const int co0 = blockIdx.y * COUT_T;
+
+    float acc[TP][COUT_T];
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+        for (int c = 0; c < COUT_T; ++c) acc[p][c] = 0.0f;
+
+    // weights / shifts are read through the constant address space so the wave-uniform loads become scalar (SMEM)
+    // loads feeding SGPR operands; as plain global loads hipcc emits one vector load per weight quad
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* wt = (const cfloat*)(wgt) + co0;
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S + ky * a.dil - a.pad;
+        const bool rowok = (unsigned)iy < (unsigned)a.H;
+        const int iyc = rowok ? iy : 0;
+#pragma unroll 1
+        for (int kx = 0; kx < K; ++kx) {
+            bool ok[TP];
+            size_t base[TP];
+#pragma unroll
+            for (int p = 0; p < TP; ++p) {
+                const int ix = (ox0 + p) * S + kx * a.dil - a.pad;
+                ok[p] = rowok && (unsigned)ix < (unsigned)a.W;
+                const int ixc = ok[p] ? ix : 0;
+                base[p] = IN_NCHW ? ((size_t)n * CIN * a.H + iyc) * a.W + ixc : (((size_t)n * a.H + iyc) * a.W + ixc) * CIN;
+            }
+            const int wk_ofs = ((ky * K + kx) * CIN) * a.COUTP;
+#pragma unroll 1
+            for (int c0 = 0; c0 < CIN; c0 += CSTEP) {
+                float v[TP][CSTEP];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {
+                    if constexpr (IN_NCHW) {
+                        v[p][0] = ok[p] ? in[base[p] + (size_t)c0 * a.H * a.W] : 0.0f;
+                    } else {
+                        const float4 t = ok[p] ? *reinterpret_cast<const float4*>(in + base[p] + c0)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[p][0] = t.x; v[p][1] = t.y; v[p][2] = t.z; v[p][3] = t.w;
+                    }
+                }
+                const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(wk_ofs + c0 * a.COUTP);
+#pragma unroll
+                for (int ci = 0; ci < CSTEP; ++ci) {
+#pragma unroll
+                    for (int c = 0; c < COUT_T; ++c) {
+                        const float wv = wq[ci * a.COUTP + c];  // wave-uniform -> scalar load
+#pragma unroll
+                        for (int p = 0; p < TP; ++p) acc[p][c] = fmaf(v[p][ci], wv, acc[p][c]);
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+
+    // epilogue: folded-BN shift / bias, optional FPN term (bilinear x2 of `up`, net.py:60,65), optional ReLU, store
+    int uy0 = 0, uy1 = 0;
+    float ly = 0.0f;
+    if (up) up2_taps(oy, a.up_h, uy0, uy1, ly);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+        const int ox = ox0 + p;
+        if (ox >= a.Wo) break;
+        float r[COUT_T];
+#pragma unroll
+        for (int c = 0; c < COUT_T; ++c) r[c] = acc[p][c] + shift[co0 + c];
+        if (up) {
+            int ux0, ux1;
+            float lx;
+            up2_taps(ox, a.up_w, ux0, ux1, lx);
+            const float* u00 = up + (((size_t)n * a.up_h + uy0) * a.up_w + ux0) * a.COUTP + co0;
+            const float* u01 = up + (((size_t)n * a.up_h + uy0) * a.up_w + ux1) * a.COUTP + co0;
+            const float* u10 = up + (((size_t)n * a.up_h + uy1) * a.up_w + ux0) * a.COUTP + co0;
+            const float* u11 = up + (((size_t)n * a.up_h + uy1) * a.up_w + ux1) * a.COUTP + co0;
+            const float hy = 1.0f - ly, hx = 1.0f - lx;
+#pragma unroll
+            for (int c = 0; c < COUT_T; ++c)  // ATen: h0*(w0*a + w1*b) + h1*(w0*c + w1*d); the sum is upsample + conv
+                r[c] = (hy * (hx * u00[c] + lx * u01[c]) + ly * (hx * u10[c] + lx * u11[c])) + r[c];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int c = 0; c < COUT_T; ++c) r[c] = fmaxf(r[c], 0.0f);
+        }
+        if (OUT_NCHW) {
+#pragma unroll
+            for (int c = 0; c < COUT_T; ++c)
+                if (co0 + c < a.cout) out[(((size_t)n * a.cout + co0 + c) * a.Ho + oy) * a.Wo + ox] = r[c];
+        } else {
+            float* o = out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.cout + co0;
+#pragma unroll
+            for (int c = 0; c < COUT_T; c += 4)
+                if (co0 + c < a.cout) *reinterpret_cast<float4*>(o + c) = make_float4(r[c], r[c + 1], r[c + 2], r[c + 3]);
+        }
+    }
+}
+
+// ---- LDS-tiled variant for channels-last inputs ------------------------------------------------------------------------
+// The direct kernel above reads 16 bytes per lane at a CIN*4-byte stride: the lines it touches are evicted from the
+// 32 KB L1 before the neighbouring taps / channel chunks come back for them, so every access re-fetches 128 B from L2
+// (measured: 8-14 TFLOP/s).  Here a workgroup owns a 16x16 tile of output pixels: per chunk of CC input channels it
+// stages the (16*S + halo)^2 input patch in LDS with coalesced float4 loads (zero-filled outside the image), then every
+// thread computes ONE output pixel x ALL COUT output channels from ds_read_b128's (pixel pitch CC+4 words: conflict
+// free) and wave-uniform SGPR weights: 2*COUT packed FMAs per LDS read.
+template <int CIN, int CC, int COUT, int COUTP, int K, int S, bool OUT_NCHW, bool UP>
+__global__ __launch_bounds__(PMN_BLOCK, 4) void conv_tiled_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ up, float* __restrict__ out,
+                                                               const ConvArgs a) {
+    constexpr int TW = 16, TH = 16, CCP = CC + 4, CQ = CC / 4;
+    static_assert(CIN % CC == 0 && CC % 4 == 0 && COUT % 8 == 0, "channel tiling");
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const int co0 = blockIdx.y * COUT;  // this block's slice of the output channels (COUT of a.COUTP)
+    const cfloat* wt = (const cfloat*)(wgt) + co0;
+    const int tid = threadIdx.x, tx = tid % TW, ty = tid / TW;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int iw = (TW - 1) * S + (K - 1) * a.dil + 1, ih = (TH - 1) * S + (K - 1) * a.dil + 1;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+
+    // The FPN term (bilinear x2 of `up`, net.py:60,65) seeds the accumulators -- loaded while nothing else is live --
+    // instead of being added in the epilogue (where 64 live accumulators + 16 quads in flight spill).
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+    if constexpr (UP) {
+        const int oyc = min(oy0 + ty, a.Ho - 1), oxc = min(ox0 + tx, a.Wo - 1);
+        int uy0, uy1, ux0, ux1;
+        float ly, lx;
+        up2_taps(oyc, a.up_h, uy0, uy1, ly);
+        up2_taps(oxc, a.up_w, ux0, ux1, lx);
+        const float* u00 = up + (((size_t)n * a.up_h + uy0) * a.up_w + ux0) * COUTP + co0;
+        const float* u01 = up + (((size_t)n * a.up_h + uy0) * a.up_w + ux1) * COUTP + co0;
+        const float* u10 = up + (((size_t)n * a.up_h + uy1) * a.up_w + ux0) * COUTP + co0;
+        const float* u11 = up + (((size_t)n * a.up_h + uy1) * a.up_w + ux1) * COUTP + co0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) {
+            const float4 p00 = *reinterpret_cast<const float4*>(u00 + c), p01 = *reinterpret_cast<const float4*>(u01 + c);
+            const float4 p10 = *reinterpret_cast<const float4*>(u10 + c), p11 = *reinterpret_cast<const float4*>(u11 + c);
+            // ATen upsample_bilinear2d: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)
+            acc[c] = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+            acc[c + 1] = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+            acc[c + 2] = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+            acc[c + 3] = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+            if ((c & 4) == 4) __builtin_amdgcn_sched_barrier(0);  // 8 channels (8 x dwordx4) in flight at a time
+        }
+    }
+
+#pragma unroll 1
+    for (int cc0 = 0; cc0 < CIN; cc0 += CC) {
+        if (cc0) __syncthreads();
+        // stage: ih x iw pixels x CC channels
+        for (int idx = tid; idx < ih * iw * CQ; idx += PMN_BLOCK) {
+            const int pix = idx / CQ, q = idx - pix * CQ;
+            const int r = pix / iw, c = pix - r * iw;
+            const int gy = iy0 + r, gx = ix0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                v = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + cc0 + 4 * q);
+            *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll 1
+            for (int kx = 0; kx < K; ++kx) {
+                const float* tp = tile + ((ty * S + ky * a.dil) * iw + tx * S + kx * a.dil) * CCP;
+#pragma unroll 1
+                for (int q = 0; q < CQ; ++q) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(tp + 4 * q);
+                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                    // readfirstlane pins the (wave-uniform) weight offset in an SGPR: in some instantiations hipcc
+                    // otherwise strength-reduces it into a VGPR pointer and falls back to per-lane vector loads
+                    const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(((ky * K + kx) * CIN + cc0 + 4 * q) * COUTP);
+#pragma unroll
+                    for (int cog = 0; cog < COUT; cog += 16) {
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+                            for (int c = 0; c < (COUT < 16 ? COUT : 16); ++c)
+                                acc[cog + c] = fmaf(v[ci], wq[ci * COUTP + cog + c], acc[cog + c]);
+                        }
+                        // one 64-weight batch (4 x s_load_dwordx16) at a time: unfenced, hipcc hoists all 4*COUT weights
+                        // of the step into VGPRs and the kernel drops to one wave per SIMD
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= a.Ho || ox >= a.Wo) return;
+    const cfloat* sh = (const cfloat*)(shift) + co0;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] += sh[c];
+    if (a.relu) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaxf(acc[c], 0.0f);
+    }
+    if (OUT_NCHW) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+            if (co0 + c < a.cout) out[(((size_t)n * a.cout + co0 + c) * a.Ho + oy) * a.Wo + ox] = acc[c];
+    } else {
+        float* o = out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.cout + co0;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4)
+            if (co0 + c < a.cout) *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    }
+}
+
+template <int CIN, int CC, int COUT, int COUTP, int K, int S, bool OUT_NCHW, bool UP>
+static int launch_tiled_impl(const float* in, const float* w, const float* shift, const float* up, float* out, ConvArgs a,
+                             hipStream_t st) {
+    const int iw = 15 * S + (K - 1) * a.dil + 1;
+    const size_t lds = (size_t)iw * iw * (CC + 4) * sizeof(float);
+    if (lds > 160 * 1024) return PMN_ERR_SHAPE;
+    auto kern = conv_tiled_kernel<CIN, CC, COUT, COUTP, K, S, OUT_NCHW, UP>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return PMN_ERR_LAUNCH;
+    const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(blocks, COUTP / COUT), dim3(PMN_BLOCK), lds, st, in, w, shift, up, out, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+template <int CIN, int COUT_T, int K, int S, bool IN_NCHW, bool OUT_NCHW>
+static int launch_conv(const float* in, const float* w, const float* shift, const float* up, float* out, ConvArgs a,
+                       hipStream_t st) {
+    // TP = 4 pixels per thread when that still leaves >= ~8 waves per SIMD-quad of work, else 2
+    const long pix = (long)a.N * a.Ho * a.Wo;
+    const dim3 gy(1, (a.cout + COUT_T - 1) / COUT_T);
+    if (pix >= 1500000L) {
+        const int wg = (a.Wo + 3) / 4;
+        const long thr = (long)a.N * a.Ho * wg;
+        hipLaunchKernelGGL((conv_kernel<CIN, COUT_T, K, S, 4, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
+                           dim3(PMN_BLOCK), 0, st, in, w, shift, up, out, a);
+    } else {
+        const int wg = (a.Wo + 1) / 2;
+        const long thr = (long)a.N * a.Ho * wg;
+        hipLaunchKernelGGL((conv_kernel<CIN, COUT_T, K, S, 2, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
+                           dim3(PMN_BLOCK), 0, st, in, w, shift, up, out, a);
+    }
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+template <int CIN, int CC, int COUT, int K, int S, bool OUT_NCHW>
+static int launch_tiled(const float* in, const float* w, const float* shift, const float* up, float* out, ConvArgs a,
+                        hipStream_t st) {
+    if constexpr (K == 1 && COUT == 64 && !OUT_NCHW) {  // the FPN lateral 1x1 convs are the only users of `up`:
+        // two blocks of 32 output channels each (64 seeded accumulators + the up-sampling loads would spill)
+        if (up) return launch_tiled_impl<CIN, CC, 32, 64, K, S, OUT_NCHW, true>(in, w, shift, up, out, a, st);
+    }
+    if (up) return PMN_ERR_SHAPE;
+    return launch_tiled_impl<CIN, CC, COUT, COUT, K, S, OUT_NCHW, false>(in, w, shift, up, out, a, st);
+}
+
+// ---- fused tail of the FPN (reference models/net.py:64-67) ---------------------------------------------------------------
+//   intra = bilinear_x2(top) + inner2(half)        (1x1 conv 16 -> 64, bias)
+//   out   = output3(intra)                         (1x1 conv 64 -> 16, no bias)
+// `intra` (64 channels at half resolution: 737 MB for six 1600x1200 views) is consumed only by output3, so it never
+// leaves registers: a thread owns one pixel, builds the 64 intermediate channels in two halves of 32 (up-sampling taps
+// + SGPR-weight FMAs) and folds each half straight into the 16 outputs.
+template <int CIN, int CMID, int COUT>
+__global__ __launch_bounds__(PMN_BLOCK, 4) void fpn_tail_kernel(const float* __restrict__ x, const float* __restrict__ up,
+                                                              const float* __restrict__ w_in,
+                                                              const float* __restrict__ b_in,
+                                                              const float* __restrict__ w_out, float* __restrict__ out,
+                                                              int N, int H, int W) {
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* wi = (const cfloat*)w_in;   // [CIN][CMID]
+    const cfloat* bi = (const cfloat*)b_in;   // [CMID]
+    const cfloat* wo = (const cfloat*)w_out;  // [CMID][COUT]
+    const size_t total = (size_t)N * H * W;
+    const size_t gid = (size_t)blockIdx.x * PMN_BLOCK + threadIdx.x;
+    if (gid >= total) return;
+    const int ox = (int)(gid % W), oy = (int)((gid / W) % H), n = (int)(gid / ((size_t)W * H));
+    const int uh = H / 2, uw = W / 2;
+
+    float xin[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(x + gid * CIN + c);
+        xin[c] = t.x; xin[c + 1] = t.y; xin[c + 2] = t.z; xin[c + 3] = t.w;
+    }
+    int uy0, uy1, ux0, ux1;
+    float ly, lx;
+    up2_taps(oy, uh, uy0, uy1, ly);
+    up2_taps(ox, uw, ux0, ux1, lx);
+    const float* u00 = up + (((size_t)n * uh + uy0) * uw + ux0) * CMID;
+    const float* u01 = up + (((size_t)n * uh + uy0) * uw + ux1) * CMID;
+    const float* u10 = up + (((size_t)n * uh + uy1) * uw + ux0) * CMID;
+    const float* u11 = up + (((size_t)n * uh + uy1) * uw + ux1) * CMID;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+
+    float o[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) o[c] = 0.0f;
+#pragma unroll 1
+    for (int m0 = 0; m0 < CMID; m0 += 32) {
+        float t[32];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const float4 p00 = *reinterpret_cast<const float4*>(u00 + m0 + c), p01 = *reinterpret_cast<const float4*>(u01 + m0 + c);
+            const float4 p10 = *reinterpret_cast<const float4*>(u10 + m0 + c), p11 = *reinterpret_cast<const float4*>(u11 + m0 + c);
+            t[c] = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+            t[c + 1] = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+            t[c + 2] = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+            t[c + 3] = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+            if ((c & 4) == 4) __builtin_amdgcn_sched_barrier(0);
+        }
+        // inner conv: t[c] = up + (sum_ci x[ci]*w[ci][m0+c] + b)   (same association as net.py:65: upsample + inner2(x))
+#pragma unroll
+        for (int cg = 0; cg < 32; cg += 16) {
+            float s[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) s[c] = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s[c] = fmaf(xin[ci], wi[ci * CMID + m0 + cg + c], s[c]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[cg + c] = t[cg + c] + (s[c] + bi[m0 + cg + c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // output conv on this half of the intermediate channels
+#pragma unroll
+        for (int cm = 0; cm < 32; cm += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) o[c] = fmaf(t[cm + k], wo[(m0 + cm + k) * COUT + c], o[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4)
+        *reinterpret_cast<float4*>(out + gid * COUT + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+}
+
+// x [N,H,W,16] (conv4 output), up [N,H/2,W/2,64] (previous FPN level), w_in [16][64] / b_in [64] (inner2, pack_conv layout),
+// w_out [64][16] (output3, pack_conv layout) -> out [N,H,W,16].
+extern "C" int pmn_fpn_tail(const float* x, const float* up, const float* w_in, const float* b_in, const float* w_out,
+                            float* out, int N, int H, int W, int cin, int cmid, int cout, void* stream) {
+    if (!x || !up || !w_in || !b_in || !w_out || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMN_ERR_ARG;
+    if (cin != 16 || cmid != 64 || cout != 16) return PMN_ERR_SHAPE;
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL((fpn_tail_kernel<16, 64, 16>), dim3((unsigned)((total + PMN_BLOCK - 1) / PMN_BLOCK)), dim3(PMN_BLOCK), 0,
+                       (hipStream_t)stream, x, up, w_in, b_in, w_out, out, N, H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// in: [N,H,W,CIN] (or [N,CIN,H,W] when in_nchw); weights packed [K][K][CIN][COUTP] with COUTP = cout rounded up to the
+// channel tile (8 if cout <= 8 else 16), BatchNorm scale folded in; shift[COUTP]; up: optional [N,up_h,up_w,cout] map that
+// is bilinearly up-sampled x2 and added before the ReLU; out: [N,Ho,Wo,cout] (or [N,cout,Ho,Wo] when out_nchw).
+extern "C" int pmn_conv2d(const float* in, const float* weights, const float* shift, const float* up, float* out, int N,
+                          int H, int W, int cin, int cout, int K, int stride, int pad, int dil, int relu, int in_nchw,
+                          int out_nchw, int up_h, int up_w, void* stream) {
+    if (!in || !weights || !shift || !out) return PMN_ERR_ARG;
+    if (N < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || stride < 1 || dil < 1 || pad < 0) return PMN_ERR_ARG;
+    ConvArgs a;
+    a.N = N; a.H = H; a.W = W;
+    a.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+    a.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+    const int tile = cout <= 8 ? 8 : 16;
+    a.COUTP = (cout + tile - 1) / tile * tile;
+    a.cout = cout; a.pad = pad; a.dil = dil; a.relu = relu; a.up_h = up_h; a.up_w = up_w;
+    if (a.Ho < 1 || a.Wo < 1) return PMN_ERR_ARG;
+    if (up && (out_nchw || a.COUTP != cout || up_h * 2 != a.Ho || up_w * 2 != a.Wo)) return PMN_ERR_ARG;
+    if (!out_nchw && (cout % 4) != 0) return PMN_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define PMN_CONV(CI, T, KK, SS, INN, OUTN) return launch_conv<CI, T, KK, SS, INN, OUTN>(in, weights, shift, up, out, a, st)
+    if (in_nchw) {
+        if (out_nchw) return PMN_ERR_SHAPE;
+        if (cin == 3 && K == 3 && stride == 1 && tile == 8) PMN_CONV(3, 8, 3, 1, true, false);
+        if (cin == 1 && K == 3 && stride == 1 && tile == 8) PMN_CONV(1, 8, 3, 1, true, false);
+        return PMN_ERR_SHAPE;
+    }
+#define PMN_TILED(CI, CCH, CO, KK, SS, OUTN) return launch_tiled<CI, CCH, CO, KK, SS, OUTN>(in, weights, shift, up, out, a, st)
+    if (out_nchw) {  // offset heads: channels-last feature in, planar [B,2K,h,w] offsets out (cout padded to 16 / 32)
+        if (K != 3 || stride != 1) return PMN_ERR_SHAPE;
+        if (a.COUTP == 8) {
+            if (cin == 64) PMN_TILED(64, 8, 8, 3, 1, true);
+            if (cin == 32) PMN_TILED(32, 8, 8, 3, 1, true);
+            if (cin == 16) PMN_TILED(16, 8, 8, 3, 1, true);
+        } else if (a.COUTP == 16) {
+            if (cin == 64) PMN_TILED(64, 8, 16, 3, 1, true);
+            if (cin == 32) PMN_TILED(32, 8, 16, 3, 1, true);
+            if (cin == 16) PMN_TILED(16, 8, 16, 3, 1, true);
+        } else if (a.COUTP == 32) {
+            if (cin == 64) PMN_TILED(64, 8, 32, 3, 1, true);
+            if (cin == 32) PMN_TILED(32, 8, 32, 3, 1, true);
+            if (cin == 16) PMN_TILED(16, 8, 32, 3, 1, true);
+        } else if (a.COUTP == 48) {
+            if (cin == 64) PMN_TILED(64, 8, 48, 3, 1, true);
+            if (cin == 32) PMN_TILED(32, 8, 48, 3, 1, true);
+            if (cin == 16) PMN_TILED(16, 8, 48, 3, 1, true);
+        }
+        return PMN_ERR_SHAPE;
+    }
+    if (a.COUTP != cout) return PMN_ERR_SHAPE;
+    if (K == 3 && stride == 1 && dil == 1) {
+        if (cin == 8 && cout == 8) PMN_TILED(8, 8, 8, 3, 1, false);
+        if (cin == 16 && cout == 8) PMN_TILED(16, 16, 8, 3, 1, false);
+        if (cin == 16 && cout == 16) PMN_TILED(16, 16, 16, 3, 1, false);
+        if (cin == 32 && cout == 32) PMN_TILED(32, 16, 32, 3, 1, false);
+        if (cin == 64 && cout == 64) PMN_TILED(64, 16, 64, 3, 1, false);
+    } else if (K == 5 && stride == 2 && dil == 1) {
+        if (cin == 8 && cout == 16) PMN_TILED(8, 8, 16, 5, 2, false);
+        if (cin == 16 && cout == 32) PMN_TILED(16, 8, 32, 5, 2, false);
+        if (cin == 32 && cout == 64) PMN_TILED(32, 8, 64, 5, 2, false);
+    } else if (K == 1 && stride == 1) {
+        if (cin == 16 && cout == 64) PMN_TILED(16, 16, 64, 1, 1, false);
+        if (cin == 32 && cout == 64) PMN_TILED(32, 16, 64, 1, 1, false);
+        if (cin == 64 && cout == 64) PMN_TILED(64, 16, 64, 1, 1, false);
+        if (cin == 64 && cout == 32) PMN_TILED(64, 16, 32, 1, 1, false);
+        if (cin == 64 && cout == 16) PMN_TILED(64, 16, 16, 1, 1, false);
+    }
+#undef PMN_TILED
+#undef PMN_CONV
+    return PMN_ERR_SHAPE;
+}

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, params
 from ._lib import PmnError
 from .module import ConvBnReLU
 from .patchmatch import PatchMatch
@@ -35,6 +35,47 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+
+    # ---- HIP execution (pmn_conv2d): same parameters, channels-last activations, BN/ReLU/FPN-add fused ----------------
+    _SPEC = [(3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1),
+             (3, 1, 1)]  # (kernel, stride, pad) of conv0..conv10
+
+    def _packed(self):
+        """Device copies of the conv weights in pmn_conv2d layout (BatchNorm folded), cached until a parameter changes."""
+        srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
+        key = params.versions(srcs)
+        if getattr(self, "_pack_key", None) != key:
+            dev = self.output1.weight.device
+            pk = {}
+            for i in range(11):
+                m = getattr(self, f"conv{i}")
+                w, s = params.pack_conv(m.conv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
+                                        eps=m.bn.eps)
+                pk[f"conv{i}"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            for name in ("output1", "inner1", "inner2", "output2", "output3"):
+                m = getattr(self, name)
+                w, s = params.pack_conv(m.weight, bias=m.bias)
+                pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            self._pack, self._pack_key = pk, key
+        return self._pack
+
+    def forward_hip(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
+        """x [N,3,H,W] -> {3: [N,H/8,W/8,64], 2: [N,H/4,W/4,32], 1: [N,H/2,W/2,16]} CHANNELS-LAST (inference only)."""
+        pk = self._packed()
+        t = x.contiguous()
+        feats = {}
+        for i, (k, s, p) in enumerate(self._SPEC):
+            w, sh = pk[f"conv{i}"]
+            t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True, in_nchw=(i == 0))
+            if i in (4, 7, 10):
+                feats[i] = t
+        half, quarter, eighth = feats[4], feats[7], feats[10]
+        out = {3: ops.conv2d(eighth, *pk["output1"], 64, 1)}
+        top = ops.conv2d(quarter, *pk["inner1"], 64, 1, up=eighth)       # upsample(conv10) + inner1(conv7)
+        out[2] = ops.conv2d(top, *pk["output2"], 32, 1)
+        # output3(upsample(intra) + inner2(conv4)) in one kernel: the 64-channel half-resolution map stays in registers
+        out[1] = ops.fpn_tail(half, top, pk["inner2"][0], pk["inner2"][1], pk["output3"][0])
+        return out
 
     def forward(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
         half = self.conv4(self.conv3(self.conv2(self.conv1(self.conv0(x)))))
@@ -98,6 +139,8 @@ class PatchmatchNet(nn.Module):
         # Run FeatureNet once on the N+1 images stacked along the batch axis when they share a size (same per-sample
         # arithmetic, N+1 times fewer launches).  Set False to mirror the reference's per-image loop exactly.
         self.batch_feature_extraction = True
+        # FeatureNet through the HIP convolutions (pmn_conv2d, fp32, channels-last) instead of MIOpen; False = PyTorch-ROCm.
+        self.hip_feature_net = True
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         """Accepts both plain and ``module.``-prefixed (nn.DataParallel) checkpoints (reference eval.py:33-35)."""
@@ -109,8 +152,14 @@ class PatchmatchNet(nn.Module):
         """Per-view feature pyramids.  ``stacked`` (a dict) additionally receives {stage: [V*B,C,h,w]} when all views
         went through FeatureNet as one batch (view-major), so the caller can change layout in one pass."""
         same = all(im.shape == images[0].shape for im in images)
+        B = images[0].shape[0]
+        if self.hip_feature_net and same and images[0].is_cuda:
+            f = self.feature.forward_hip(torch.cat(images, dim=0) if len(images) > 1 else images[0])
+            if stacked is not None:
+                stacked.update({("nhwc", s): t for s, t in f.items()})
+            # per-view NCHW-shaped views over the channels-last storage (no copy)
+            return [{s: t[i * B:(i + 1) * B].permute(0, 3, 1, 2) for s, t in f.items()} for i in range(len(images))]
         if self.batch_feature_extraction and same and len(images) > 1:
-            B = images[0].shape[0]
             f = self.feature(torch.cat(images, dim=0))
             if stacked is not None:
                 stacked.update(f)
@@ -164,8 +213,13 @@ class PatchmatchNet(nn.Module):
             dbg = [] if debug is not None else None
             pm: PatchMatch = getattr(self, f"patchmatch_{stage}")
             ref_nhwc = src_nhwc = None
-            if stage in stacked:  # one layout pass for all views of the stage
+            if ("nhwc", stage) in stacked:  # HIP FeatureNet: already channels-last
+                allv = stacked[("nhwc", stage)]
+            elif stage in stacked:  # one layout pass for all views of the stage
                 allv = ops.nchw_to_nhwc(stacked[stage].contiguous())
+            else:
+                allv = None
+            if allv is not None:
                 ref_nhwc = allv[:batch]
                 src_nhwc = allv[batch:].view(len(src_features), batch, *allv.shape[1:])
             depths, score, view_weights = pm(

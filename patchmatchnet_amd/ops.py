@@ -71,7 +71,13 @@ def _host_i32(a: np.ndarray, n: int, name: str):
 
 
 def nchw_to_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[B,C,h,w] -> [B,h,w,C] (fresh tensor, or into ``out`` which may be a slice of a stacked buffer)."""
+    """[B,C,h,w] -> [B,h,w,C] (fresh tensor, or into ``out`` which may be a slice of a stacked buffer).  An input that is
+    already channels-last in memory (an NCHW-shaped view of NHWC storage) is returned as a view, without a copy."""
+    if out is None and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous():
+        v = x.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+        x = x.contiguous()
     _dev(x, "x")
     B, C, h, w = x.shape
     if out is None:
@@ -94,7 +100,7 @@ def stack_sources_nhwc(src_features: Sequence[torch.Tensor]) -> torch.Tensor:
     for i, f in enumerate(src_features):
         if tuple(f.shape) != (B, C, hs, ws):
             raise PmnError("all source feature maps of one stage must share a shape")
-        nchw_to_nhwc(f, buf[i])
+        nchw_to_nhwc(f.contiguous(), buf[i])
     return buf
 
 
@@ -273,4 +279,51 @@ def differentiable_warping(src_fea: torch.Tensor, src_proj: torch.Tensor, ref_pr
         check(_lib.lib().pmn_differentiable_warping(src_fea.data_ptr(), proj.data_ptr(), depth_samples.data_ptr(), B, C,
                                                     D, h, w, hs, ws, out.data_ptr(), _stream(out)),
               "pmn_differentiable_warping")
+    return out
+
+
+def conv2d(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, K: int, stride: int = 1, pad: int = 0,
+           dil: int = 1, relu: bool = False, up: Optional[torch.Tensor] = None, in_nchw: bool = False,
+           out_nchw: bool = False) -> torch.Tensor:
+    """pmn_conv2d: x [N,H,W,cin] (or [N,cin,H,W] with in_nchw) -> [N,Ho,Wo,cout] (or [N,cout,Ho,Wo] with out_nchw);
+    ``weights`` / ``shift`` from params.pack_conv (device tensors); ``up`` [N,Ho/2,Wo/2,cout] is up-sampled x2 and added."""
+    _dev(x, "x")
+    _dev(weights, "weights")
+    _dev(shift, "shift")
+    if in_nchw:
+        N, cin, H, W = x.shape
+    else:
+        N, H, W, cin = x.shape
+    if tuple(weights.shape[:3]) != (K, K, cin) or shift.numel() != weights.shape[3]:
+        raise PmnError("conv2d: packed weights do not match the input")
+    Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    out = torch.empty((N, cout, Ho, Wo) if out_nchw else (N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    up_h = up_w = 0
+    if up is not None:
+        _dev(up, "up")
+        if tuple(up.shape) != (N, Ho // 2, Wo // 2, cout) or Ho % 2 or Wo % 2:
+            raise PmnError("conv2d: `up` must be [N,Ho/2,Wo/2,cout]")
+        up_h, up_w = up.shape[1], up.shape[2]
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), _ptr(up), out.data_ptr(), N, H, W,
+                                    cin, cout, K, stride, pad, dil, 1 if relu else 0, 1 if in_nchw else 0,
+                                    1 if out_nchw else 0, up_h, up_w, _stream(x)), "pmn_conv2d")
+    return out
+
+
+def fpn_tail(x: torch.Tensor, up: torch.Tensor, w_in: torch.Tensor, b_in: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
+    """pmn_fpn_tail: output3(bilinear_x2(up) + inner2(x)) (reference models/net.py:64-67); x [N,H,W,16], up [N,H/2,W/2,64]
+    -> [N,H,W,16]; weights in params.pack_conv layout."""
+    for n_, t_ in (("x", x), ("up", up), ("w_in", w_in), ("b_in", b_in), ("w_out", w_out)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    cmid, cout = up.shape[3], w_out.shape[3]
+    if tuple(up.shape) != (N, H // 2, W // 2, cmid) or tuple(w_in.shape) != (1, 1, cin, cmid) or \
+            tuple(w_out.shape) != (1, 1, cmid, cout):
+        raise PmnError("fpn_tail: inconsistent shapes")
+    out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_fpn_tail(x.data_ptr(), up.data_ptr(), w_in.data_ptr(), b_in.data_ptr(), w_out.data_ptr(),
+                                      out.data_ptr(), N, H, W, cin, cmid, cout, _stream(x)), "pmn_fpn_tail")
     return out

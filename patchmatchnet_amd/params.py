@@ -79,3 +79,26 @@ def evaluation_table(neighbors: int, dilation: int) -> np.ndarray:
 def versions(tensors: Sequence[torch.Tensor]) -> List[int]:
     """Cheap cache key: autograd version counters + storage addresses of the source tensors."""
     return [t._version for t in tensors] + [t.data_ptr() for t in tensors]
+
+
+def pack_conv(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
+    """Conv2d weight [cout,cin,K,K] (+ BatchNorm2d tensors (weight, bias, running_mean, running_var) or a conv bias) ->
+    (float32 [K,K,cin,coutp], float32 [coutp]) in the layout pmn_conv2d reads; BatchNorm folded in float64."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        s = g / np.sqrt(v + eps)
+        w = w * s[:, None, None, None]
+        shift = b - m * s
+    elif bias is not None:
+        shift = _np64(bias)
+    else:
+        shift = np.zeros(cout)
+    tile = 8 if cout <= 8 else 16
+    coutp = (cout + tile - 1) // tile * tile
+    wp = np.zeros((K, K, cin, coutp), np.float64)
+    wp[..., :cout] = w.transpose(2, 3, 1, 0)
+    sp = np.zeros(coutp, np.float64)
+    sp[:cout] = shift
+    return np.ascontiguousarray(wp.astype(np.float32)), np.ascontiguousarray(sp.astype(np.float32))

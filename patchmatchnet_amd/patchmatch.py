@@ -188,8 +188,24 @@ class PatchMatch(nn.Module):
         nn.init.constant_(self.eval_conv.bias, 0.0)
         self.feature_weight_net = FeatureWeightNet(evaluate_neighbors, self.G)
 
+        # offset heads through pmn_conv2d (True) or MIOpen (False)
+        self.hip_offset_heads = True
+        self._heads = None
+        self._heads_key = None
         self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
         self._etable = params.evaluation_table(evaluate_neighbors, self.dilation)
+
+    def _packed_heads(self):
+        srcs = [self.propa_conv.weight, self.propa_conv.bias, self.eval_conv.weight, self.eval_conv.bias]
+        key = params.versions(srcs)
+        if self._heads is None or key != self._heads_key:
+            dev = self.eval_conv.weight.device
+            pk = {}
+            for name, m in (("propa", self.propa_conv), ("eval", self.eval_conv)):
+                w, s = params.pack_conv(m.weight, bias=m.bias)
+                pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            self._heads, self._heads_key = pk, key
+        return self._heads
 
     def forward(self, ref_feature: torch.Tensor, src_features: List[torch.Tensor], ref_proj: torch.Tensor,
                 src_projs: List[torch.Tensor], depth_min: torch.Tensor, depth_max: torch.Tensor, depth: torch.Tensor,
@@ -207,16 +223,23 @@ class PatchMatch(nn.Module):
             raise PmnError("patchmatchnet_amd.PatchMatch runs on a ROCm GPU only (no CPU fallback)")
         device = ref_feature.device
         batch, _, height, width = ref_feature.size()
-        ref_feature = ref_feature.contiguous()
 
         propagate_any = self.propagate_neighbors > 0 and not (self.stage == 1 and self.patchmatch_iteration == 1)
-        propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None
-        eval_offsets = self.eval_conv(ref_feature).contiguous()
-
         if ref_nhwc is None:
             ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
+        if self.hip_offset_heads:
+            # offset heads as HIP convolutions on the channels-last reference feature, planar [B,2K,h,w] output
+            pk = self._packed_heads()
+            propa_offsets = ops.conv2d(ref_nhwc, *pk["propa"], 2 * self.propagate_neighbors, 3, 1, self.dilation,
+                                       self.dilation, out_nchw=True) if propagate_any else None
+            eval_offsets = ops.conv2d(ref_nhwc, *pk["eval"], 2 * self.evaluate_neighbors, 3, 1, self.dilation,
+                                      self.dilation, out_nchw=True)
+        else:
+            ref_feature = ref_feature.contiguous()
+            propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None
+            eval_offsets = self.eval_conv(ref_feature).contiguous()
         if src_nhwc is None:
-            src_nhwc = ops.stack_sources_nhwc([f.detach().contiguous() for f in src_features])
+            src_nhwc = ops.stack_sources_nhwc([f.detach() for f in src_features])
         rel_proj = ops.relative_projection(src_projs, ref_proj)
         depth_min = depth_min.float().contiguous()
         depth_max = depth_max.float().contiguous()

@@ -54,6 +54,12 @@ ref = None
 with torch.no_grad():
     ref = fn(x)
 print("baseline nchw            %.3f ms" % timeit(lambda: fn(x)))
+with torch.no_grad():
+    o = fn.forward_hip(x)
+err = max(float((o[s].permute(0, 3, 1, 2) - ref[s]).abs().max() / ref[s].abs().max()) for s in (1, 2, 3))
+print("HIP pmn_conv2d           %.3f ms   max rel diff vs baseline %.2e" % (timeit(lambda: fn.forward_hip(x)), err))
+if os.environ.get("FN_ONLY_HIP"):
+    sys.exit(0)
 for name, f in [("folded conv+bias, relu  ", lambda: run_folded(x, False)), ("folded miopen conv_relu ", lambda: run_folded(x, True))]:
     try:
         with torch.no_grad(): o = f()

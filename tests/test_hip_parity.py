@@ -46,7 +46,7 @@ def _configs(kw):
 
 def test_library_is_the_compute_path():
     P = _gpu()
-    assert P.lib().pmn_abi_version() == 2
+    assert P.lib().pmn_abi_version() == P._lib.ABI_VERSION
     with pytest.raises(P.PmnError):  # CPU tensors are refused, there is no fallback
         P.ops.nchw_to_nhwc(torch.zeros(1, 4, 4, 4))
 
@@ -209,6 +209,71 @@ def test_view_weight_upsampling_shift_matches_materialised():
     for x, y in zip(a[0], b[0]):
         assert torch.equal(x, y)
     assert torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("cin,cout,K,stride,pad,dil,in_nchw,out_nchw,up", [
+    (3, 8, 3, 1, 1, 1, True, False, False), (1, 8, 3, 1, 1, 1, True, False, False), (8, 8, 3, 1, 1, 1, False, False, False),
+    (8, 16, 5, 2, 2, 1, False, False, False), (16, 16, 3, 1, 1, 1, False, False, False),
+    (16, 32, 5, 2, 2, 1, False, False, False), (32, 32, 3, 1, 1, 1, False, False, False),
+    (32, 64, 5, 2, 2, 1, False, False, False), (64, 64, 3, 1, 1, 1, False, False, False),
+    (64, 64, 1, 1, 0, 1, False, False, False), (32, 64, 1, 1, 0, 1, False, False, True),
+    (16, 64, 1, 1, 0, 1, False, False, True), (64, 32, 1, 1, 0, 1, False, False, False),
+    (64, 16, 1, 1, 0, 1, False, False, False), (64, 32, 3, 1, 2, 2, False, True, False),
+    (32, 18, 3, 1, 4, 4, False, True, False), (16, 18, 3, 1, 6, 6, False, True, False), (16, 8, 3, 1, 1, 1, False, False, False)])
+def test_conv2d_against_torch(cin, cout, K, stride, pad, dil, in_nchw, out_nchw, up):
+    """pmn_conv2d (direct fp32 conv, folded BatchNorm, fused ReLU / FPN add) vs F.conv2d + BatchNorm + ReLU on the device,
+    on odd sizes (ragged tiles, borders)."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin * 100 + cout)
+    N, H, W = 2, 38 if stride == 1 else 44, 54 if stride == 1 else 60
+    x = torch.randn(N, cin, H, W, generator=gen).to(DEV)
+    wt = (0.2 * torch.randn(cout, cin, K, K, generator=gen)).to(DEV)
+    use_bn = not out_nchw and not up
+    bias = None if use_bn else (0.1 * torch.randn(cout, generator=gen)).to(DEV)
+    bn = None
+    if use_bn:
+        bn = ((0.5 + torch.rand(cout, generator=gen)).to(DEV), (0.1 * torch.randn(cout, generator=gen)).to(DEV),
+              (0.1 * torch.randn(cout, generator=gen)).to(DEV), (0.5 + torch.rand(cout, generator=gen)).to(DEV))
+    ref = torch.nn.functional.conv2d(x, wt, bias, stride, pad, dil)
+    if use_bn:
+        ref = torch.nn.functional.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    upt = None
+    if up:
+        upt = torch.randn(N, ref.shape[2] // 2, ref.shape[3] // 2, cout, generator=gen).to(DEV)
+        ref = torch.nn.functional.interpolate(upt.permute(0, 3, 1, 2), scale_factor=2.0, mode="bilinear",
+                                              align_corners=False) + ref
+    relu = use_bn
+    if relu:
+        ref = torch.relu(ref)
+    w, s = PP.pack_conv(wt, bn=bn, bias=bias)
+    xin = x if in_nchw else x.permute(0, 2, 3, 1).contiguous()
+    out = P.ops.conv2d(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(s).to(DEV), cout, K, stride, pad, dil, relu=relu,
+                       up=upt, in_nchw=in_nchw, out_nchw=out_nchw)
+    got = out if out_nchw else out.permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1.0))
+    assert err < 2e-5, err
+
+
+def test_featurenet_hip_matches_miopen():
+    """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels."""
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
+    with torch.no_grad():
+        ref = model.feature(x)
+        got = model.feature.forward_hip(x)
+    for s in (1, 2, 3):
+        a, b = got[s].permute(0, 3, 1, 2), ref[s]
+        assert a.shape == b.shape
+        assert float((a - b).abs().max() / b.abs().max()) < 5e-5, s
+    # and against the reference's own CPU FeatureNet outputs stored in the fixture
+    for v in range(int(g["n_views"])):
+        for s in (1, 2, 3):
+            gold = g[f"feature_{v}_s{s}"]
+            assert GU.abs_err(n(got[s][v:v + 1].permute(0, 3, 1, 2)), gold) / np.abs(gold).max() < 1e-4
 
 
 # ---- BASELINE-size checks -------------------------------------------------------------------------------------------
