@@ -126,6 +126,12 @@ int pmn_conv2d(const float *in, const float *weights, const float *shift, const 
 int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float *b_in, const float *w_out, float *out,
                  int N, int H, int W, int cin, int cmid, int cout, void *stream);
 
+/* ConvTranspose2d(8, 8, k=3, stride=2, padding=1, output_padding=1, bias=False) + BatchNorm + ReLU of the Refinement net
+ * (reference models/net.py:86-88, 114).  in [N,Hi,Wi,8]; weights DEVICE float [3][3][8][8] ([ky][kx][ci][co], BatchNorm scale
+ * folded in: patchmatchnet_amd/params.py pack_deconv); shift DEVICE float[8] -> out [N,2Hi,2Wi,8]. */
+int pmn_deconv3x3s2(const float *in, const float *weights, const float *shift, float *out, int N, int Hi, int Wi, int cin,
+                    int cout, int relu, void *stream);
+
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */
 int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, const float *depth, int B, int C,

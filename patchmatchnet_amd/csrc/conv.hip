@@ -405,6 +405,68 @@ extern "C" int pmn_fpn_tail(const float* x, const float* up, const float* w_in, 
     return PMN_OK;
 }
 
+// ---- ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1) + folded BatchNorm + ReLU (Refinement, net.py:86-88,114) ----
+// out[oy,ox,co] = sum_{ky,kx,ci} in[(oy+1-ky)/2, (ox+1-kx)/2, ci] * w[ky][kx][ci][co] over the (ky,kx) for which both
+// source coordinates are integral and in range: one tap for even coordinates (k=1), two for odd ones (k=0 and k=2).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(PMN_BLOCK) void deconv3x3s2_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                               const float* __restrict__ shift, float* __restrict__ out,
+                                                               int N, int Hi, int Wi, int relu) {
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* wt = (const cfloat*)wgt;
+    const cfloat* sh = (const cfloat*)shift;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t total = (size_t)N * Ho * Wo;
+    const size_t gid = (size_t)blockIdx.x * PMN_BLOCK + threadIdx.x;
+    if (gid >= total) return;
+    const int ox = (int)(gid % Wo), oy = (int)((gid / Wo) % Ho), n = (int)(gid / ((size_t)Wo * Ho));
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = oy + 1 - ky;
+        const bool yok = ty >= 0 && !(ty & 1) && (ty >> 1) < Hi;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ox + 1 - kx;
+            const bool ok = yok && tx >= 0 && !(tx & 1) && (tx >> 1) < Wi;
+            const float* ip = in + (((size_t)n * Hi + (ok ? (ty >> 1) : 0)) * Wi + (ok ? (tx >> 1) : 0)) * CIN;
+            float v[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; c += 4) {
+                const float4 t = ok ? *reinterpret_cast<const float4*>(ip + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[ci], wt[((ky * 3 + kx) * CIN + ci) * COUT + c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        acc[c] += sh[c];
+        if (relu) acc[c] = fmaxf(acc[c], 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4)
+        *reinterpret_cast<float4*>(out + gid * COUT + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+}
+
+// in [N,Hi,Wi,8], weights [3][3][8][8] (ConvTranspose2d weight [ci][co][ky][kx] re-ordered, BatchNorm scale folded in),
+// shift [8] -> out [N,2*Hi,2*Wi,8]
+extern "C" int pmn_deconv3x3s2(const float* in, const float* weights, const float* shift, float* out, int N, int Hi, int Wi,
+                               int cin, int cout, int relu, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || Hi < 1 || Wi < 1) return PMN_ERR_ARG;
+    if (cin != 8 || cout != 8) return PMN_ERR_SHAPE;
+    const size_t total = (size_t)N * Hi * Wi * 4;
+    hipLaunchKernelGGL((deconv3x3s2_kernel<8, 8>), dim3((unsigned)((total + PMN_BLOCK - 1) / PMN_BLOCK)), dim3(PMN_BLOCK), 0,
+                       (hipStream_t)stream, in, weights, shift, out, N, Hi, Wi, relu);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
 // in: [N,H,W,CIN] (or [N,CIN,H,W] when in_nchw); weights packed [K][K][CIN][COUTP] with COUTP = cout rounded up to the
 // channel tile (8 if cout <= 8 else 16), BatchNorm scale folded in; shift[COUTP]; up: optional [N,up_h,up_w,cout] map that
 // is bilinearly up-sampled x2 and added before the ReLU; out: [N,Ho,Wo,cout] (or [N,cout,Ho,Wo] when out_nchw).
@@ -434,23 +496,29 @@ extern "C" int pmn_conv2d(const float* in, const float* weights, const float* sh
 #define PMN_TILED(CI, CCH, CO, KK, SS, OUTN) return launch_tiled<CI, CCH, CO, KK, SS, OUTN>(in, weights, shift, up, out, a, st)
     if (out_nchw) {  // offset heads: channels-last feature in, planar [B,2K,h,w] offsets out (cout padded to 16 / 32)
         if (K != 3 || stride != 1) return PMN_ERR_SHAPE;
+        // 16 output channels per workgroup (grid.y = coutp/16): the coarsest stage has only ~120 tiles of 16x16 pixels,
+        // so the channel split is what fills the chip
+#define PMN_HEAD(CI, CP) return launch_tiled_impl<CI, 8, (CP < 16 ? CP : 16), CP, 3, 1, true, false>(in, weights, shift, up, out, a, st)
+        if (up) return PMN_ERR_SHAPE;
         if (a.COUTP == 8) {
-            if (cin == 64) PMN_TILED(64, 8, 8, 3, 1, true);
-            if (cin == 32) PMN_TILED(32, 8, 8, 3, 1, true);
-            if (cin == 16) PMN_TILED(16, 8, 8, 3, 1, true);
+            if (cin == 8) PMN_HEAD(8, 8);
+            if (cin == 64) PMN_HEAD(64, 8);
+            if (cin == 32) PMN_HEAD(32, 8);
+            if (cin == 16) PMN_HEAD(16, 8);
         } else if (a.COUTP == 16) {
-            if (cin == 64) PMN_TILED(64, 8, 16, 3, 1, true);
-            if (cin == 32) PMN_TILED(32, 8, 16, 3, 1, true);
-            if (cin == 16) PMN_TILED(16, 8, 16, 3, 1, true);
+            if (cin == 64) PMN_HEAD(64, 16);
+            if (cin == 32) PMN_HEAD(32, 16);
+            if (cin == 16) PMN_HEAD(16, 16);
         } else if (a.COUTP == 32) {
-            if (cin == 64) PMN_TILED(64, 8, 32, 3, 1, true);
-            if (cin == 32) PMN_TILED(32, 8, 32, 3, 1, true);
-            if (cin == 16) PMN_TILED(16, 8, 32, 3, 1, true);
+            if (cin == 64) PMN_HEAD(64, 32);
+            if (cin == 32) PMN_HEAD(32, 32);
+            if (cin == 16) PMN_HEAD(16, 32);
         } else if (a.COUTP == 48) {
-            if (cin == 64) PMN_TILED(64, 8, 48, 3, 1, true);
-            if (cin == 32) PMN_TILED(32, 8, 48, 3, 1, true);
-            if (cin == 16) PMN_TILED(16, 8, 48, 3, 1, true);
+            if (cin == 64) PMN_HEAD(64, 48);
+            if (cin == 32) PMN_HEAD(32, 48);
+            if (cin == 16) PMN_HEAD(16, 48);
         }
+#undef PMN_HEAD
         return PMN_ERR_SHAPE;
     }
     if (a.COUTP != cout) return PMN_ERR_SHAPE;

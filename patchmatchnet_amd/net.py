@@ -102,6 +102,44 @@ class Refinement(nn.Module):
         self.conv3 = ConvBnReLU(in_channels=16, out_channels=8)
         self.res = nn.Conv2d(8, 1, kernel_size=3, padding=1, bias=False)
 
+    def _packed(self):
+        srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
+        key = params.versions(srcs)
+        if getattr(self, "_pack_key", None) != key:
+            dev = self.res.weight.device
+
+            def bn_of(m):
+                return (m.weight, m.bias, m.running_mean, m.running_var)
+
+            pk = {}
+            for name in ("conv0", "conv1", "conv2", "conv3"):
+                m = getattr(self, name)
+                w, s = params.pack_conv(m.conv.weight, bn=bn_of(m.bn), eps=m.bn.eps)
+                pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            w, s = params.pack_deconv(self.deconv.weight, bn=bn_of(self.bn), eps=self.bn.eps)
+            pk["deconv"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            w, s = params.pack_conv(self.res.weight)
+            pk["res"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            self._pack, self._pack_key = pk, key
+        return self._pack
+
+    def forward_hip(self, img: torch.Tensor, depth_0: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor
+                    ) -> torch.Tensor:
+        """Same computation through pmn_conv2d / pmn_deconv3x3s2 (channels-last, BatchNorm + ReLU fused)."""
+        pk = self._packed()
+        b = depth_min.size()[0]
+        lo = depth_min.view(b, 1, 1, 1)
+        span = (depth_max - depth_min).view(b, 1, 1, 1)
+        d = ((depth_0 - lo) / span).contiguous()
+        img_feat = ops.conv2d(img.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True)      # [B,H,W,8]
+        t = ops.conv2d(d, *pk["conv1"], 8, 3, 1, 1, relu=True, in_nchw=True)                             # [B,H/2,W/2,8]
+        t = ops.conv2d(t, *pk["conv2"], 8, 3, 1, 1, relu=True)
+        up = ops.deconv3x3s2(t, *pk["deconv"], relu=True)                                                # [B,H,W,8]
+        t = ops.conv2d(torch.cat((up, img_feat), dim=3), *pk["conv3"], 8, 3, 1, 1, relu=True)
+        res = ops.conv2d(t, *pk["res"], 1, 3, 1, 1, out_nchw=True)                                       # [B,1,H,W]
+        d = F.interpolate(d, scale_factor=2.0, mode="nearest") + res
+        return d * span + lo
+
     def forward(self, img: torch.Tensor, depth_0: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor
                 ) -> torch.Tensor:
         b = depth_min.size()[0]
@@ -237,7 +275,10 @@ class PatchmatchNet(nn.Module):
                 depth_shift = 1
                 vw_shift = vw_shift + 1 if view_weights.shape[-1] != depths[-1].shape[-1] else 1
 
-        depth = self.upsample_net(ref_image, depth, depth_min, depth_max)
+        if self.hip_feature_net and ref_image.is_cuda:
+            depth = self.upsample_net.forward_hip(ref_image, depth, depth_min, depth_max)
+        else:
+            depth = self.upsample_net(ref_image, depth, depth_min, depth_max)
         if ref_width != orig_width or ref_height != orig_height:
             depth = F.interpolate(depth, size=[orig_height, orig_width], mode="bilinear", align_corners=False)
         depth_patchmatch[0] = [depth]

@@ -327,3 +327,17 @@ def fpn_tail(x: torch.Tensor, up: torch.Tensor, w_in: torch.Tensor, b_in: torch.
         check(_lib.lib().pmn_fpn_tail(x.data_ptr(), up.data_ptr(), w_in.data_ptr(), b_in.data_ptr(), w_out.data_ptr(),
                                       out.data_ptr(), N, H, W, cin, cmid, cout, _stream(x)), "pmn_fpn_tail")
     return out
+
+
+def deconv3x3s2(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """pmn_deconv3x3s2: ConvTranspose2d(k3,s2,p1,op1) + folded BN + ReLU; x [N,Hi,Wi,8] -> [N,2Hi,2Wi,8]."""
+    _dev(x, "x")
+    _dev(weights, "weights")
+    _dev(shift, "shift")
+    N, Hi, Wi, cin = x.shape
+    cout = weights.shape[3]
+    out = torch.empty((N, 2 * Hi, 2 * Wi, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_deconv3x3s2(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, Hi, Wi, cin,
+                                         cout, 1 if relu else 0, _stream(x)), "pmn_deconv3x3s2")
+    return out

@@ -102,3 +102,18 @@ def pack_conv(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
     sp = np.zeros(coutp, np.float64)
     sp[:cout] = shift
     return np.ascontiguousarray(wp.astype(np.float32)), np.ascontiguousarray(sp.astype(np.float32))
+
+
+def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
+    """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
+    pmn_deconv3x3s2; BatchNorm folded in float64."""
+    w = _np64(weight)
+    cin, cout, K, _ = w.shape
+    shift = np.zeros(cout)
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        s = g / np.sqrt(v + eps)
+        w = w * s[None, :, None, None]
+        shift = b - m * s
+    return (np.ascontiguousarray(w.transpose(2, 3, 0, 1).astype(np.float32)),
+            np.ascontiguousarray(shift.astype(np.float32)))

@@ -276,6 +276,21 @@ def test_featurenet_hip_matches_miopen():
             assert GU.abs_err(n(got[s][v:v + 1].permute(0, 3, 1, 2)), gold) / np.abs(gold).max() < 1e-4
 
 
+def test_refinement_hip_matches_miopen():
+    """Refinement through pmn_conv2d / pmn_deconv3x3s2 vs the same module on PyTorch-ROCm (MIOpen)."""
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    img = t(g["image_0"])
+    gen = torch.Generator().manual_seed(5)
+    d0 = (425.0 + 510.0 * torch.rand(1, 1, img.shape[2] // 2, img.shape[3] // 2, generator=gen)).to(DEV)
+    with torch.no_grad():
+        ref = model.upsample_net(img, d0, t(g["depth_min"]), t(g["depth_max"]))
+        got = model.upsample_net.forward_hip(img, d0, t(g["depth_min"]), t(g["depth_max"]))
+    assert got.shape == ref.shape
+    assert float(((got - ref).abs() / ref.abs()).max()) < 1e-5
+
+
 # ---- BASELINE-size checks -------------------------------------------------------------------------------------------
 
 def _fullsize_stage(P, stage, n_src, H, W, params, kw, seed=0):
