@@ -11,6 +11,7 @@
 // pixel (NHWC: 16 contiguous bytes) and issues 4*COUT_T*TP FMAs whose weight operands are wave-uniform, i.e. scalar
 // loads / SGPR operands ([K][K][CIN][COUTP] weight layout: the COUT_T weights of one input channel are contiguous).
 // fp32 throughout (fp16/bf16 features are not parity-safe); BatchNorm is folded into the weights in fp64.
+#include <cstdlib>
 #include <cstring>
 
 #include "pmn_common.hpp"
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(PMN_BLOCK, 4) void conv_tiled_kernel(const float* _
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ up, float* __restrict__ out,
                                                                const ConvArgs a) {
-    constexpr int TW = 16, TH = 16, CCP = CC + 4, CQ = CC / 4;
+    // pixel pitch in LDS: CC+4 words makes unit-stride ds_read_b128 conflict-free; stride-2 readers do best unpadded
+    constexpr int TW = 16, TH = 16, CCP = (S == 2 && CC == 4) ? 4 : CC + 4, CQ = CC / 4;
     static_assert(CIN % CC == 0 && CC % 4 == 0 && COUT % 8 == 0, "channel tiling");
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
@@ -264,7 +266,7 @@ template <int CIN, int CC, int COUT, int COUTP, int K, int S, bool OUT_NCHW, boo
 static int launch_tiled_impl(const float* in, const float* w, const float* shift, const float* up, float* out, ConvArgs a,
                              hipStream_t st) {
     const int iw = 15 * S + (K - 1) * a.dil + 1;
-    const size_t lds = (size_t)iw * iw * (CC + 4) * sizeof(float);
+    const size_t lds = (size_t)iw * iw * ((S == 2 && CC == 4) ? 4 : CC + 4) * sizeof(float);
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
     auto kern = conv_tiled_kernel<CIN, CC, COUT, COUTP, K, S, OUT_NCHW, UP>;
     if (lds > 48 * 1024 &&
@@ -321,30 +323,54 @@ __global__ __launch_bounds__(PMN_BLOCK, 4) void fpn_tail_kernel(const float* __r
                                                               const float* __restrict__ b_in,
                                                               const float* __restrict__ w_out, float* __restrict__ out,
                                                               int N, int H, int W) {
+    // 16x16 output tile per workgroup; the x tile and the 10x10 patch of `up` it samples are staged in LDS with coalesced
+    // float4 loads (per-lane 16-byte reads at a 64/256-byte stride thrash the L1, see conv_tiled_kernel)
+    constexpr int TW = 16, TH = 16, XP = CIN + 4, UPW = 10, UPP = CMID + 4;
+    __shared__ float4 xs4[TW * TH * XP / 4];
+    __shared__ float4 us4[UPW * UPW * UPP / 4];
+    float* xs = reinterpret_cast<float*>(xs4);
+    float* us = reinterpret_cast<float*>(us4);
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* wi = (const cfloat*)w_in;   // [CIN][CMID]
     const cfloat* bi = (const cfloat*)b_in;   // [CMID]
     const cfloat* wo = (const cfloat*)w_out;  // [CMID][COUT]
-    const size_t total = (size_t)N * H * W;
-    const size_t gid = (size_t)blockIdx.x * PMN_BLOCK + threadIdx.x;
-    if (gid >= total) return;
-    const int ox = (int)(gid % W), oy = (int)((gid / W) % H), n = (int)(gid / ((size_t)W * H));
+    const int tid = threadIdx.x, tx = tid % TW, ty = tid / TW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
     const int uh = H / 2, uw = W / 2;
+    const int uy_base = max(oy0 / 2 - 1, 0), ux_base = max(ox0 / 2 - 1, 0);
 
+    for (int idx = tid; idx < TW * TH * (CIN / 4); idx += PMN_BLOCK) {
+        const int pix = idx / (CIN / 4), q = idx - pix * (CIN / 4);
+        const int gy = min(oy0 + pix / TW, H - 1), gx = min(ox0 + pix % TW, W - 1);
+        *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) =
+            *reinterpret_cast<const float4*>(x + (((size_t)n * H + gy) * W + gx) * CIN + 4 * q);
+    }
+    for (int idx = tid; idx < UPW * UPW * (CMID / 4); idx += PMN_BLOCK) {
+        const int pix = idx / (CMID / 4), q = idx - pix * (CMID / 4);
+        const int gy = min(uy_base + pix / UPW, uh - 1), gx = min(ux_base + pix % UPW, uw - 1);
+        *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) =
+            *reinterpret_cast<const float4*>(up + (((size_t)n * uh + gy) * uw + gx) * CMID + 4 * q);
+    }
+    __syncthreads();
+
+    const int oy = min(oy0 + ty, H - 1), ox = min(ox0 + tx, W - 1);
     float xin[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; c += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(x + gid * CIN + c);
+        const float4 t = *reinterpret_cast<const float4*>(xs + tid * XP + c);
         xin[c] = t.x; xin[c + 1] = t.y; xin[c + 2] = t.z; xin[c + 3] = t.w;
     }
     int uy0, uy1, ux0, ux1;
     float ly, lx;
     up2_taps(oy, uh, uy0, uy1, ly);
     up2_taps(ox, uw, ux0, ux1, lx);
-    const float* u00 = up + (((size_t)n * uh + uy0) * uw + ux0) * CMID;
-    const float* u01 = up + (((size_t)n * uh + uy0) * uw + ux1) * CMID;
-    const float* u10 = up + (((size_t)n * uh + uy1) * uw + ux0) * CMID;
-    const float* u11 = up + (((size_t)n * uh + uy1) * uw + ux1) * CMID;
+    const float* u00 = us + ((uy0 - uy_base) * UPW + (ux0 - ux_base)) * UPP;
+    const float* u01 = us + ((uy0 - uy_base) * UPW + (ux1 - ux_base)) * UPP;
+    const float* u10 = us + ((uy1 - uy_base) * UPW + (ux0 - ux_base)) * UPP;
+    const float* u11 = us + ((uy1 - uy_base) * UPW + (ux1 - ux_base)) * UPP;
     const float hy = 1.0f - ly, hx = 1.0f - lx;
 
     float o[COUT];
@@ -387,9 +413,10 @@ __global__ __launch_bounds__(PMN_BLOCK, 4) void fpn_tail_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (oy0 + ty >= H || ox0 + tx >= W) return;
+    float* op = out + (((size_t)n * H + oy) * W + ox) * COUT;
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4)
-        *reinterpret_cast<float4*>(out + gid * COUT + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    for (int c = 0; c < COUT; c += 4) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
 }
 
 // x [N,H,W,16] (conv4 output), up [N,H/2,W/2,64] (previous FPN level), w_in [16][64] / b_in [64] (inner2, pack_conv layout),
@@ -398,9 +425,9 @@ extern "C" int pmn_fpn_tail(const float* x, const float* up, const float* w_in, 
                             float* out, int N, int H, int W, int cin, int cmid, int cout, void* stream) {
     if (!x || !up || !w_in || !b_in || !w_out || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMN_ERR_ARG;
     if (cin != 16 || cmid != 64 || cout != 16) return PMN_ERR_SHAPE;
-    const size_t total = (size_t)N * H * W;
-    hipLaunchKernelGGL((fpn_tail_kernel<16, 64, 16>), dim3((unsigned)((total + PMN_BLOCK - 1) / PMN_BLOCK)), dim3(PMN_BLOCK), 0,
-                       (hipStream_t)stream, x, up, w_in, b_in, w_out, out, N, H, W);
+    const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL((fpn_tail_kernel<16, 64, 16>), dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, x, up, w_in, b_in,
+                       w_out, out, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -522,6 +549,23 @@ extern "C" int pmn_conv2d(const float* in, const float* weights, const float* sh
         return PMN_ERR_SHAPE;
     }
     if (a.COUTP != cout) return PMN_ERR_SHAPE;
+    static const int split64 = getenv("PMN_CONV_SPLIT") ? atoi(getenv("PMN_CONV_SPLIT")) : 32;
+    static const int cc5 = getenv("PMN_CONV_CC5") ? atoi(getenv("PMN_CONV_CC5")) : 4;
+    if (!up && split64 == 32) {
+        if (K == 3 && stride == 1 && dil == 1 && cin == 64 && cout == 64)
+            return launch_tiled_impl<64, 16, 32, 64, 3, 1, false, false>(in, weights, shift, up, out, a, st);
+        if (K == 5 && stride == 2 && cin == 32 && cout == 64) {
+            if (cc5 == 4) return launch_tiled_impl<32, 4, 32, 64, 5, 2, false, false>(in, weights, shift, up, out, a, st);
+            return launch_tiled_impl<32, 8, 32, 64, 5, 2, false, false>(in, weights, shift, up, out, a, st);
+        }
+        if (K == 1 && cin == 64 && cout == 64)
+            return launch_tiled_impl<64, 16, 32, 64, 1, 1, false, false>(in, weights, shift, up, out, a, st);
+    }
+    if (!up && cc5 == 4 && K == 5 && stride == 2) {
+        if (cin == 8 && cout == 16) return launch_tiled_impl<8, 4, 16, 16, 5, 2, false, false>(in, weights, shift, up, out, a, st);
+        if (cin == 16 && cout == 32) return launch_tiled_impl<16, 4, 32, 32, 5, 2, false, false>(in, weights, shift, up, out, a, st);
+        if (cin == 32 && cout == 64) return launch_tiled_impl<32, 4, 64, 64, 5, 2, false, false>(in, weights, shift, up, out, a, st);
+    }
     if (K == 3 && stride == 1 && dil == 1) {
         if (cin == 8 && cout == 8) PMN_TILED(8, 8, 8, 3, 1, false);
         if (cin == 16 && cout == 8) PMN_TILED(16, 16, 8, 3, 1, false);
