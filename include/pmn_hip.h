@@ -132,6 +132,12 @@ int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float
 int pmn_deconv3x3s2(const float *in, const float *weights, const float *shift, float *out, int N, int Hi, int Wi, int cin,
                     int cout, int relu, void *stream);
 
+/* Relative projections of every (stage, batch element, source view): rel = P_src @ inverse(P_ref) with
+ * P = [[K_s @ E[:3,:4]], [E[3,:]]] and K_s = K with rows 0,1 scaled by scale0 * 2^stage (reference models/net.py:225-231,
+ * models/module.py:148).  intrinsics [B,V,3,3], extrinsics [B,V,4,4] (view 0 = reference) -> rel [nstages,B,V-1,4,4]. */
+int pmn_stage_projections(const float *intrinsics, const float *extrinsics, int B, int V, int nstages, float scale0,
+                          float *rel, void *stream);
+
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */
 int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, const float *depth, int B, int C,

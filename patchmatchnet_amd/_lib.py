@@ -39,6 +39,7 @@ SIGNATURES = {
     "pmn_conv2d": [_fp, _fp, _fp, _fp, _fp] + [_i] * 14 + [_s],
     "pmn_fpn_tail": [_fp] * 6 + [_i] * 6 + [_s],
     "pmn_deconv3x3s2": [_fp] * 4 + [_i] * 6 + [_s],
+    "pmn_stage_projections": [_fp, _fp, _i, _i, _i, _f, _fp, _s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
 }
 

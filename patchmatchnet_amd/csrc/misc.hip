@@ -106,3 +106,76 @@ extern "C" int pmn_differentiable_warping(const float* src_nchw, const float* re
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
+
+// ---- per-stage relative projections (reference models/net.py:225-231 + models/module.py:148) -------------------------------
+// For every stage s (scale 1/8, 1/4, 1/2 ...), batch b and source view v:
+//   K_s = K with rows 0,1 scaled;  P = [[K_s E[:3,:4]], [E[3,:]]] ;  rel = P_src @ inverse(P_ref)
+// One thread per (stage, b, v).  The products are formed in fp32 exactly like the reference's torch.matmul (k-ascending
+// FMA-free sums); the 4x4 inverse is a double-precision Gauss-Jordan with partial pivoting rounded to fp32 (torch.inverse
+// is an fp32 LU; both are within ~1e-7 relative of the exact inverse, i.e. ~1e-4 px at 800-px coordinates).
+__global__ void stage_projections_kernel(const float* __restrict__ intr, const float* __restrict__ extr, int B, int V,
+                                         int nstages, float scale0, float* __restrict__ rel) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nsrc = V - 1;
+    if (i >= nstages * B * nsrc) return;
+    const int v = i % nsrc + 1, b = (i / nsrc) % B, s = i / (nsrc * B);
+    float scale = scale0;
+    for (int k = 0; k < s; ++k) scale *= 2.0f;
+    float P[2][16];
+    for (int w = 0; w < 2; ++w) {
+        const int view = w == 0 ? 0 : v;
+        const float* K = intr + ((size_t)b * V + view) * 9;
+        const float* E = extr + ((size_t)b * V + view) * 16;
+        for (int r = 0; r < 3; ++r) {
+            const float k0 = r < 2 ? K[r * 3 + 0] * scale : K[r * 3 + 0];
+            const float k1 = r < 2 ? K[r * 3 + 1] * scale : K[r * 3 + 1];
+            const float k2 = r < 2 ? K[r * 3 + 2] * scale : K[r * 3 + 2];
+            for (int c = 0; c < 4; ++c) P[w][r * 4 + c] = (k0 * E[0 * 4 + c] + k1 * E[1 * 4 + c]) + k2 * E[2 * 4 + c];
+        }
+        for (int c = 0; c < 4; ++c) P[w][12 + c] = E[12 + c];
+    }
+    // inverse of P[0] in fp64
+    double A[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            A[r][c] = (double)P[0][r * 4 + c];
+            A[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r)
+            if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+        for (int c = 0; c < 8; ++c) {
+            const double t = A[col][c];
+            A[col][c] = A[piv][c];
+            A[piv][c] = t;
+        }
+        const double inv = 1.0 / A[col][col];
+        for (int c = 0; c < 8; ++c) A[col][c] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = A[r][col];
+            for (int c = 0; c < 8; ++c) A[r][c] -= f * A[col][c];
+        }
+    }
+    float* o = rel + (((size_t)s * B + b) * nsrc + (v - 1)) * 16;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc = acc + P[1][r * 4 + k] * (float)A[k][4 + c];
+            o[r * 4 + c] = acc;
+        }
+}
+
+// intrinsics [B,V,3,3], extrinsics [B,V,4,4] (view 0 = reference) -> rel [nstages, B, V-1, 4, 4]; stage s uses intrinsics
+// rows 0,1 scaled by scale0 * 2^s (reference net.py:221-232: scale0 = 0.125, three stages)
+extern "C" int pmn_stage_projections(const float* intrinsics, const float* extrinsics, int B, int V, int nstages,
+                                     float scale0, float* rel, void* stream) {
+    if (!intrinsics || !extrinsics || !rel || B < 1 || V < 2 || nstages < 1) return PMN_ERR_ARG;
+    const int total = nstages * B * (V - 1);
+    hipLaunchKernelGGL(stage_projections_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, intrinsics,
+                       extrinsics, B, V, nstages, scale0, rel);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

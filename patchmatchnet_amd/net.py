@@ -59,14 +59,22 @@ class FeatureNet(nn.Module):
             self._pack, self._pack_key = pk, key
         return self._pack
 
-    def forward_hip(self, x: torch.Tensor) -> Dict[int, torch.Tensor]:
-        """x [N,3,H,W] -> {3: [N,H/8,W/8,64], 2: [N,H/4,W/4,32], 1: [N,H/2,W/2,16]} CHANNELS-LAST (inference only)."""
+    def forward_hip(self, x) -> Dict[int, torch.Tensor]:
+        """x [N,3,H,W], or a list of same-size [B,3,H,W] images (stacked view-major without a torch.cat copy: the first
+        layer writes each image's output into its slice) -> {3: [N,H/8,W/8,64], 2: [N,H/4,W/4,32], 1: [N,H/2,W/2,16]}
+        CHANNELS-LAST (inference only)."""
         pk = self._packed()
-        t = x.contiguous()
+        imgs = list(x) if isinstance(x, (list, tuple)) else [x]
+        B, _, H, W = imgs[0].shape
+        t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
+        for i, im in enumerate(imgs):
+            ops.conv2d(im.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True, out=t[i * B:(i + 1) * B])
         feats = {}
         for i, (k, s, p) in enumerate(self._SPEC):
+            if i == 0:
+                continue
             w, sh = pk[f"conv{i}"]
-            t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True, in_nchw=(i == 0))
+            t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)
             if i in (4, 7, 10):
                 feats[i] = t
         half, quarter, eighth = feats[4], feats[7], feats[10]
@@ -179,6 +187,8 @@ class PatchmatchNet(nn.Module):
         self.batch_feature_extraction = True
         # FeatureNet through the HIP convolutions (pmn_conv2d, fp32, channels-last) instead of MIOpen; False = PyTorch-ROCm.
         self.hip_feature_net = True
+        # all relative projections from one pmn_stage_projections launch; False = the reference's torch op sequence
+        self.hip_projections = True
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         """Accepts both plain and ``module.``-prefixed (nn.DataParallel) checkpoints (reference eval.py:33-35)."""
@@ -192,7 +202,7 @@ class PatchmatchNet(nn.Module):
         same = all(im.shape == images[0].shape for im in images)
         B = images[0].shape[0]
         if self.hip_feature_net and same and images[0].is_cuda:
-            f = self.feature.forward_hip(torch.cat(images, dim=0) if len(images) > 1 else images[0])
+            f = self.feature.forward_hip(images)
             if stacked is not None:
                 stacked.update({("nhwc", s): t for s, t in f.items()})
             # per-view NCHW-shaped views over the channels-last storage (no copy)
@@ -238,14 +248,20 @@ class PatchmatchNet(nn.Module):
 
         scale = 0.125
         depth_shift, vw_shift = 0, 0
+        # relative projections of all stages in one launch (replaces ~40 tiny ATen kernels per forward)
+        rel_all = ops.stage_projections(intrinsics, extrinsics, self.stages - 1, scale) if self.hip_projections else None
         for stage in range(self.stages - 1, 0, -1):
-            # stage projection matrices (reference models/net.py:225-231)
-            intrinsics_l = intrinsics.clone()
-            intrinsics_l[:, :, :2] *= scale
-            proj = extrinsics.clone()
-            proj[:, :, :3, :4] = torch.matmul(intrinsics_l, extrinsics[:, :, :3, :4])
-            proj_l = torch.unbind(proj, 1)
-            ref_proj, src_proj = proj_l[0], proj_l[1:]
+            # stage projection matrices (reference models/net.py:225-231): the reference's op sequence is only run when
+            # hip_projections is off; otherwise PatchMatch receives rel_proj and never reads ref_proj / src_projs
+            if rel_all is None:
+                intrinsics_l = intrinsics.clone()
+                intrinsics_l[:, :, :2] *= scale
+                proj = extrinsics.clone()
+                proj[:, :, :3, :4] = torch.matmul(intrinsics_l, extrinsics[:, :, :3, :4])
+                proj_l = torch.unbind(proj, 1)
+                ref_proj, src_proj = proj_l[0], proj_l[1:]
+            else:
+                ref_proj, src_proj = extrinsics[:, 0], [extrinsics[:, i] for i in range(1, extrinsics.shape[1])]
             scale *= 2.0
 
             dbg = [] if debug is not None else None
@@ -264,7 +280,8 @@ class PatchmatchNet(nn.Module):
                 ref_feature=ref_feature[stage], src_features=[f[stage] for f in src_features], ref_proj=ref_proj,
                 src_projs=list(src_proj), depth_min=depth_min, depth_max=depth_max, depth=depth,
                 view_weights=view_weights, depth_shift=depth_shift, vw_shift=vw_shift,
-                noise=noise if stage == self.stages - 1 else None, debug=dbg, ref_nhwc=ref_nhwc, src_nhwc=src_nhwc)
+                noise=noise if stage == self.stages - 1 else None, debug=dbg, ref_nhwc=ref_nhwc, src_nhwc=src_nhwc,
+                rel_proj=None if rel_all is None else rel_all[self.stages - 1 - stage])
             if debug is not None:
                 debug[stage] = dbg
             depth_patchmatch[stage] = depths

@@ -282,9 +282,23 @@ def differentiable_warping(src_fea: torch.Tensor, src_proj: torch.Tensor, ref_pr
     return out
 
 
+def stage_projections(intrinsics: torch.Tensor, extrinsics: torch.Tensor, nstages: int = 3, scale0: float = 0.125
+                      ) -> torch.Tensor:
+    """pmn_stage_projections: intrinsics [B,V,3,3], extrinsics [B,V,4,4] -> relative projections [nstages,B,V-1,4,4]
+    (stage index 0 = coarsest, scale0; reference models/net.py:221-232 + models/module.py:148)."""
+    intrinsics = _dev(intrinsics.float().contiguous(), "intrinsics")
+    extrinsics = _dev(extrinsics.float().contiguous(), "extrinsics")
+    B, V = intrinsics.shape[:2]
+    rel = torch.empty((nstages, B, V - 1, 4, 4), dtype=torch.float32, device=intrinsics.device)
+    with torch.cuda.device(rel.device):
+        check(_lib.lib().pmn_stage_projections(intrinsics.data_ptr(), extrinsics.data_ptr(), B, V, nstages, float(scale0),
+                                               rel.data_ptr(), _stream(rel)), "pmn_stage_projections")
+    return rel
+
+
 def conv2d(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, K: int, stride: int = 1, pad: int = 0,
            dil: int = 1, relu: bool = False, up: Optional[torch.Tensor] = None, in_nchw: bool = False,
-           out_nchw: bool = False) -> torch.Tensor:
+           out_nchw: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pmn_conv2d: x [N,H,W,cin] (or [N,cin,H,W] with in_nchw) -> [N,Ho,Wo,cout] (or [N,cout,Ho,Wo] with out_nchw);
     ``weights`` / ``shift`` from params.pack_conv (device tensors); ``up`` [N,Ho/2,Wo/2,cout] is up-sampled x2 and added."""
     _dev(x, "x")
@@ -298,7 +312,13 @@ def conv2d(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: in
         raise PmnError("conv2d: packed weights do not match the input")
     Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
-    out = torch.empty((N, cout, Ho, Wo) if out_nchw else (N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    shape = (N, cout, Ho, Wo) if out_nchw else (N, Ho, Wo, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, "out")
+        if tuple(out.shape) != shape:
+            raise PmnError("conv2d: bad `out` shape")
     up_h = up_w = 0
     if up is not None:
         _dev(up, "up")

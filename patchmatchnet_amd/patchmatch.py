@@ -211,12 +211,15 @@ class PatchMatch(nn.Module):
                 src_projs: List[torch.Tensor], depth_min: torch.Tensor, depth_max: torch.Tensor, depth: torch.Tensor,
                 view_weights: torch.Tensor, depth_shift: int = 0, vw_shift: int = 0, noise: Optional[torch.Tensor] = None,
                 debug: Optional[list] = None, ref_nhwc: Optional[torch.Tensor] = None,
-                src_nhwc: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+                src_nhwc: Optional[torch.Tensor] = None, rel_proj: Optional[torch.Tensor] = None
+                ) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
         """Reference arguments, plus optional extras that default to reference behaviour:
         ``depth_shift`` / ``vw_shift`` = 1 read ``depth`` / ``view_weights`` given at half resolution through the
         nearest x2 up-sampling (skips materialising F.interpolate); ``noise`` pins the stage-3 random draw;
         ``debug`` (a list) receives one dict of intermediates per iteration; ``ref_nhwc`` [B,h,w,C] / ``src_nhwc``
-        [N,B,h,w,C] hand over channels-last copies the caller already made (one layout pass for all views)."""
+        [N,B,h,w,C] hand over channels-last copies the caller already made (one layout pass for all views); ``rel_proj``
+        [B,N,4,4] hands over src_proj @ inverse(ref_proj) when the caller already has it (then ref_proj / src_projs are
+        not read)."""
         if len(src_features) != len(src_projs):
             raise AssertionError("Patchmatch Evaluation: Different number of images and projection matrices")
         if not ref_feature.is_cuda:
@@ -240,7 +243,9 @@ class PatchMatch(nn.Module):
             eval_offsets = self.eval_conv(ref_feature).contiguous()
         if src_nhwc is None:
             src_nhwc = ops.stack_sources_nhwc([f.detach() for f in src_features])
-        rel_proj = ops.relative_projection(src_projs, ref_proj)
+        if rel_proj is None:
+            rel_proj = ops.relative_projection(src_projs, ref_proj)
+        rel_proj = rel_proj.contiguous()
         depth_min = depth_min.float().contiguous()
         depth_max = depth_max.float().contiguous()
 

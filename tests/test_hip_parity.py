@@ -276,6 +276,23 @@ def test_featurenet_hip_matches_miopen():
             assert GU.abs_err(n(got[s][v:v + 1].permute(0, 3, 1, 2)), gold) / np.abs(gold).max() < 1e-4
 
 
+def test_stage_projections_kernel():
+    """pmn_stage_projections vs the reference's op sequence (net.py:225-231 + module.py:148) in float64."""
+    P = _gpu()
+    intr, extr = synth.synthetic_cameras(6, 1200, 1600)
+    intr = np.repeat(intr, 2, 0)
+    extr = np.repeat(extr, 2, 0)
+    extr[1, :, :3, 3] += 5.0
+    rel = n(P.ops.stage_projections(t(intr), t(extr), 3, 0.125))
+    assert rel.shape == (3, 2, 5, 4, 4)
+    for s, scale in enumerate((0.125, 0.25, 0.5)):
+        proj = synth.stage_projections(intr, extr, scale).astype(np.float64)
+        for b in range(2):
+            for v in range(1, 6):
+                want = proj[b, v] @ np.linalg.inv(proj[b, 0])
+                assert np.abs(rel[s, b, v - 1] - want).max() / np.abs(want).max() < 2e-6
+
+
 def test_refinement_hip_matches_miopen():
     """Refinement through pmn_conv2d / pmn_deconv3x3s2 vs the same module on PyTorch-ROCm (MIOpen)."""
     P = _gpu()
