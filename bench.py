@@ -171,6 +171,20 @@ def main():
             a[0] += ms
             a[1] += nb
             a[2] += 1
+        # HBM traffic of the same launches from the committed PMC passes (profiles/pmc_traffic.json, see
+        # scripts/make_traffic_json.py for the collection + gfx950 FETCH_SIZE correction); null when not available
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tpath) and (H, W, n_src) == (1200, 1600, 5):
+            tk = json.load(open(tpath))["kernels"]
+            try:
+                per_step = 0
+                for ms, nb, tag in recs[:len(recs) // args.steps]:
+                    C_, D_ = tag.split("_")[0], tag.split("_")[1]
+                    per_step += tk[f"{C_}_{D_}_{'pixelwise' if tag.endswith('pixelwise') else 'vw'}"]["hbm_bytes_per_launch"]
+                traffic = per_step
+            except KeyError:
+                traffic = None
         line = {
             "metric": "depth-maps/sec at 1600x1200 N=5 src views", "value": round(value, 4), "unit": "depth-maps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -180,7 +194,8 @@ def main():
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence"},
             "roofline": {"bound": "hbm", "kernel": "gather_corr_kernel (pmn_warp_correlate)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 PMC, profiles/pmc_traffic.json)",
                          "launches": len(recs), "kernel_ms_per_step": round(k_ms / args.steps, 4),
                          "alg_bytes_per_step": int(k_bytes / args.steps),
                          "per_shape": {k: {"ms_avg": round(v[0] / v[2], 4),

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Turns the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE passes with
+--kernel-trace only) into profiles/pmc_traffic.json: HBM bytes per launch of every pmn_warp_correlate kernel shape.
+
+Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies
+128-byte requests at 64 bytes, i.e. reports exactly half of the bytes of a wide coalesced read stream -> doubled here.
+WRITE_SIZE is taken as reported (uncalibrated per the guide).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"gather_corr_kernel<(\d+), (\d+), (\d+), (\d+)", r["Kernel_Name"])
+        if not m or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        C, G, mode, DT = (int(x) for x in m.groups())
+        if mode == 2:
+            continue
+        vals[f"C{C}_D{DT}_{'pixelwise' if mode == 1 else 'vw'}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, v in vals.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        fk = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+        wk = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+dst = os.path.join(root, "profiles", "pmc_traffic.json")
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/kernel_bench.py at cfg-2 shapes",
+           "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE under-reports wide reads by 2x)",
+           "kernels": out}, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
