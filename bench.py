@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one full ``PatchmatchNet.forward`` (FeatureNet on MIOpen, the learned-PatchMatch hot path in HIP, refinement,
-confidence) for ONE reference view with 5 source views at 1600x1200, iterations (1,2,2) -- BASELINE.json configs[1].
+A "step" = one full ``PatchmatchNet.forward`` (FeatureNet, the learned-PatchMatch hot path, refinement, confidence -- all in
+the HIP kernels of patchmatchnet_amd/csrc) for ONE reference view with 5 source views at 1600x1200, iterations (1,2,2) -- BASELINE.json configs[1].
 Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU: reference views shard across ranks
 with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
 confidence maps closes the timed region, as the per-scan gather before fusion does in eval.

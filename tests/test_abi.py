@@ -106,3 +106,35 @@ def test_mlp_packing_folds_batchnorm():
     out = w2 @ h1 + b2
     assert (np.abs(out - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-4
     assert net.packed() is net.packed()  # cached
+
+
+def test_conv_packing_layouts():
+    """pack_conv / pack_deconv: BatchNorm folding and the [K][K][cin][coutp] layout pmn_conv2d reads."""
+    from patchmatchnet_amd import params as PP
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(18, 16, 3, 3, generator=g)
+    b = torch.randn(18, generator=g)
+    wp, sp = PP.pack_conv(w, bias=b)
+    assert wp.shape == (3, 3, 16, 32) and sp.shape == (32,)  # 18 -> padded to a multiple of 16
+    np.testing.assert_allclose(wp[1, 2, 5, :18], w[:, 5, 1, 2].numpy(), rtol=1e-7)
+    assert (wp[..., 18:] == 0).all() and (sp[18:] == 0).all()
+    np.testing.assert_allclose(sp[:18], b.numpy(), rtol=1e-7)
+    w8 = torch.randn(8, 3, 3, 3, generator=g)
+    bn = (torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g), torch.randn(8, generator=g),
+          torch.rand(8, generator=g) + 0.5)
+    wp, sp = PP.pack_conv(w8, bn=bn)
+    assert wp.shape == (3, 3, 3, 8)
+    scale = bn[0].double() / torch.sqrt(bn[3].double() + 1e-5)
+    np.testing.assert_allclose(wp[0, 0, 1], (w8[:, 1, 0, 0].double() * scale).float().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(sp, (bn[1].double() - bn[2].double() * scale).float().numpy(), rtol=1e-6, atol=1e-7)
+    # folded conv == conv + BatchNorm (eval) on the CPU
+    x = torch.randn(1, 3, 9, 9, generator=g)
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, w8, None, 1, 1), bn[2], bn[3], bn[0], bn[1], False, 0.0,
+                                         1e-5)
+    wf = torch.from_numpy(wp).permute(3, 2, 0, 1)  # back to [cout,cin,K,K]
+    got = torch.nn.functional.conv2d(x, wf, torch.from_numpy(sp), 1, 1)
+    assert float((got - ref).abs().max()) < 1e-5
+    wd = torch.randn(8, 8, 3, 3, generator=g)
+    wdp, sdp = PP.pack_deconv(wd, bn=bn)
+    assert wdp.shape == (3, 3, 8, 8)
+    np.testing.assert_allclose(wdp[2, 1, 3], (wd[3, :, 2, 1].double() * scale).float().numpy(), rtol=1e-6)
