@@ -308,6 +308,69 @@ def test_refinement_hip_matches_miopen():
     assert float(((got - ref).abs() / ref.abs()).max()) < 1e-5
 
 
+def _rand_sample(n_views, H, W, B=1, seed=0):
+    imgs = [im.repeat(B, 1, 1, 1).to(DEV) for im in synth.synthetic_images(n_views, H, W)]
+    if B > 1:
+        imgs = [torch.cat([im[:1], torch.flip(im[1:], dims=[3])], 0).contiguous() for im in imgs]
+    intr, extr = synth.synthetic_cameras(n_views, H, W)
+    return imgs, t(np.repeat(intr, B, 0)), t(np.repeat(extr, B, 0)), t(np.full(B, 425.0, np.float32)), \
+        t(np.full(B, 935.0, np.float32))
+
+
+def test_batch_of_two_equals_two_single_samples():
+    """B=2 through the whole HIP forward (FeatureNet, PatchMatch, refinement) == the two samples run one by one."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    imgs, K, E, dmin, dmax = _rand_sample(4, 96, 128, B=2)
+    noise = torch.rand(2, 48, 12, 16, generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        d2, c2, _ = model([i.clone() for i in imgs], K.clone(), E, dmin, dmax, noise=noise)
+        for b in range(2):
+            d1, c1, _ = model([i[b:b + 1].clone() for i in imgs], K[b:b + 1].clone(), E[b:b + 1], dmin[b:b + 1],
+                              dmax[b:b + 1], noise=noise[b:b + 1])
+            assert torch.equal(d1[0], d2[b]) and torch.equal(c1[0], c2[b])
+
+
+def test_sizes_not_multiple_of_8_are_resized_like_the_reference():
+    """adjust_image_dims (reference net.py:304-318): inputs are stretched to multiples of 8, intrinsics rescaled IN
+    PLACE, outputs come back at the original size."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    imgs, K, E, dmin, dmax = _rand_sample(3, 100, 130)
+    K0 = K.clone()
+    with torch.no_grad():
+        depth, conf, dpm = model(imgs, K, E, dmin, dmax)
+    assert depth.shape == (1, 1, 100, 130) and conf.shape == (1, 100, 130)
+    # 100/8 = 12.5 rounds to 12 (Python's round-half-even, as in the reference) -> 96; 130/8 = 16.25 -> 16 -> 128
+    assert imgs[0].shape[-2:] == (96, 128)  # the caller's list now holds the resized images, as with the reference
+    assert torch.allclose(K[:, :, 0], K0[:, :, 0] * (128 / 130)) and torch.allclose(K[:, :, 1], K0[:, :, 1] * (96 / 100))
+    assert bool(torch.isfinite(depth).all()) and dpm[1][-1].shape == (1, 1, 48, 64)
+
+
+@pytest.mark.parametrize("H,W,n_src", [(1056, 1920, 7), (2048, 3072, 10)])
+def test_large_configs_run_and_are_sane(H, W, n_src):
+    """BASELINE configs[2] (Tanks&Temples 1920x1056, N=7) and configs[4] (ETH3D 3072x2048, N=10) through the full forward:
+    finite outputs inside the depth range, probabilities behind the confidence in [0,1], bit-identical reruns."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    imgs, K, E, dmin, dmax = _rand_sample(n_src + 1, H, W)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        d1, c1, dpm = model(list(imgs), K.clone(), E, dmin, dmax, noise=noise)
+        d2, c2, _ = model(list(imgs), K.clone(), E, dmin, dmax, noise=noise)
+    torch.cuda.synchronize()
+    assert d1.shape == (1, 1, H, W) and c1.shape == (1, H, W)
+    assert torch.equal(d1, d2) and torch.equal(c1, c2)
+    assert bool(torch.isfinite(d1).all()) and bool(torch.isfinite(c1).all())
+    for s in (3, 2, 1):
+        for d in dpm[s]:
+            assert float(d.min()) >= 425.0 * (1 - 1e-5) and float(d.max()) <= 935.0 * (1 + 1e-5)
+    assert float(c1.min()) >= 0.0 and float(c1.max()) <= 1.0 + 1e-5
+
+
 # ---- BASELINE-size checks -------------------------------------------------------------------------------------------
 
 def _fullsize_stage(P, stage, n_src, H, W, params, kw, seed=0):
