@@ -138,6 +138,12 @@ int pmn_deconv3x3s2(const float *in, const float *weights, const float *shift, f
 int pmn_stage_projections(const float *intrinsics, const float *extrinsics, int B, int V, int nstages, float scale0,
                           float *rel, void *stream);
 
+/* Fused full-resolution stem of FeatureNet: conv0 (3->8) + conv1 (8->8), each 3x3 + BatchNorm + ReLU (reference
+ * models/net.py:17-19, 51).  img [N,3,H,W] planar; w0 [3][3][3][8] / s0 [8], w1 [3][3][8][8] / s1 [8] (pack_conv layout, device)
+ * -> out [N,H,W,8] channels-last. */
+int pmn_stem(const float *img, const float *w0, const float *s0, const float *w1, const float *s1, float *out, int N, int H,
+             int W, void *stream);
+
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */
 int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, const float *depth, int B, int C,

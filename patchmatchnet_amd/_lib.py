@@ -40,6 +40,7 @@ SIGNATURES = {
     "pmn_fpn_tail": [_fp] * 6 + [_i] * 6 + [_s],
     "pmn_deconv3x3s2": [_fp] * 4 + [_i] * 6 + [_s],
     "pmn_stage_projections": [_fp, _fp, _i, _i, _i, _f, _fp, _s],
+    "pmn_stem": [_fp] * 6 + [_i] * 3 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
 }
 

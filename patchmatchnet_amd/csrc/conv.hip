@@ -311,6 +311,96 @@ static int launch_tiled(const float* in, const float* w, const float* shift, con
     return launch_tiled_impl<CIN, CC, COUT, COUT, K, S, OUT_NCHW, false>(in, w, shift, up, out, a, st);
 }
 
+// ---- fused stem: conv0 (3 -> 8) + conv1 (8 -> 8), both 3x3 / BatchNorm / ReLU, at full resolution (net.py:17-19, 51) -----
+// The two full-resolution layers are bandwidth-shaped (8 channels): fusing them keeps conv0's 8-channel map (61 MB per
+// 1600x1200 image) out of HBM.  Workgroup = 16x16 output pixels: the planar 20x20x3 input patch goes to LDS, conv0 is
+// evaluated on the 18x18 halo patch into LDS (positions outside the image are ZERO: conv1 pads conv0's output map, not the
+// image), then every thread produces one conv1 pixel from ds_read_b128's and SGPR weights.
+__global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w0,
+                                                         const float* __restrict__ s0, const float* __restrict__ w1,
+                                                         const float* __restrict__ s1, float* __restrict__ out, int N,
+                                                         int H, int W) {
+    constexpr int TW = 16, TH = 16, IW = 20, IWP = 21, MW = 18, MP = 12;  // input patch 20x20 (pitch 21), mid 18x18 (12 words/px)
+    __shared__ float xin[3 * IW * IWP];
+    __shared__ float4 mid4[MW * MW * MP / 4];
+    float* mid = reinterpret_cast<float*>(mid4);
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
+    const cfloat* cs0 = (const cfloat*)s0;
+    const cfloat* cw1 = (const cfloat*)w1;  // [3][3][8][8]
+    const cfloat* cs1 = (const cfloat*)s1;
+    const int tid = threadIdx.x, tx = tid % TW, ty = tid / TW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+
+    for (int idx = tid; idx < 3 * IW * IW; idx += PMN_BLOCK) {
+        const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+        const int gy = oy0 - 2 + r, gx = ox0 - 2 + q;
+        float v = 0.0f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
+        xin[(c * IW + r) * IWP + q] = v;
+    }
+    __syncthreads();
+    for (int m = tid; m < MW * MW; m += PMN_BLOCK) {
+        const int r = m / MW, q = m - r * MW;
+        const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = xin[(ci * IW + r + ky) * IWP + q + kx];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, cw0[((ky * 3 + kx) * 3 + ci) * 8 + c], acc[c]);
+                }
+        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = inside ? fmaxf(acc[c] + cs0[c], 0.0f) : 0.0f;
+        *reinterpret_cast<float4*>(mid + m * MP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(mid + m * MP + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* mp = mid + ((ty + ky) * MW + tx + kx) * MP;
+            const float4 a = *reinterpret_cast<const float4*>(mp), b = *reinterpret_cast<const float4*>(mp + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = fmaf(v[ci], cw1[((ky * 3 + kx) * 8 + ci) * 8 + c], o[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= H || ox >= W) return;
+    float* op = out + (((size_t)n * H + oy) * W + ox) * 8;
+    *reinterpret_cast<float4*>(op) = make_float4(fmaxf(o[0] + cs1[0], 0.f), fmaxf(o[1] + cs1[1], 0.f), fmaxf(o[2] + cs1[2], 0.f),
+                                                 fmaxf(o[3] + cs1[3], 0.f));
+    *reinterpret_cast<float4*>(op + 4) = make_float4(fmaxf(o[4] + cs1[4], 0.f), fmaxf(o[5] + cs1[5], 0.f),
+                                                     fmaxf(o[6] + cs1[6], 0.f), fmaxf(o[7] + cs1[7], 0.f));
+}
+
+// img [N,3,H,W] planar; w0 [3][3][3][8] / s0 [8] and w1 [3][3][8][8] / s1 [8] in pack_conv layout -> out [N,H,W,8]
+extern "C" int pmn_stem(const float* img, const float* w0, const float* s0, const float* w1, const float* s1, float* out,
+                        int N, int H, int W, void* stream) {
+    if (!img || !w0 || !s0 || !w1 || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, w0, s0, w1, s1, out, N, H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
 // ---- fused tail of the FPN (reference models/net.py:64-67) ---------------------------------------------------------------
 //   intra = bilinear_x2(top) + inner2(half)        (1x1 conv 16 -> 64, bias)
 //   out   = output3(intra)                         (1x1 conv 64 -> 16, no bias)

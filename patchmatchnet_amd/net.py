@@ -67,11 +67,11 @@ class FeatureNet(nn.Module):
         imgs = list(x) if isinstance(x, (list, tuple)) else [x]
         B, _, H, W = imgs[0].shape
         t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
-        for i, im in enumerate(imgs):
-            ops.conv2d(im.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True, out=t[i * B:(i + 1) * B])
+        for i, im in enumerate(imgs):  # conv0 + conv1 fused (pmn_stem)
+            ops.stem(im.contiguous(), *pk["conv0"], *pk["conv1"], out=t[i * B:(i + 1) * B])
         feats = {}
         for i, (k, s, p) in enumerate(self._SPEC):
-            if i == 0:
+            if i < 2:
                 continue
             w, sh = pk[f"conv{i}"]
             t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)

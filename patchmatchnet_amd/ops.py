@@ -361,3 +361,23 @@ def deconv3x3s2(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, rel
         check(_lib.lib().pmn_deconv3x3s2(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, Hi, Wi, cin,
                                          cout, 1 if relu else 0, _stream(x)), "pmn_deconv3x3s2")
     return out
+
+
+def stem(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1: torch.Tensor, s1: torch.Tensor,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pmn_stem: FeatureNet conv0 + conv1 fused; img [N,3,H,W] -> [N,H,W,8] (optionally into ``out``)."""
+    for n_, t_ in (("img", img), ("w0", w0), ("s0", s0), ("w1", w1), ("s1", s1)):
+        _dev(t_, n_)
+    N, c, H, W = img.shape
+    if c != 3 or tuple(w0.shape) != (3, 3, 3, 8) or tuple(w1.shape) != (3, 3, 8, 8):
+        raise PmnError("stem: expects a 3-channel image and 3->8->8 weights")
+    if out is None:
+        out = torch.empty((N, H, W, 8), dtype=torch.float32, device=img.device)
+    else:
+        _dev(out, "out")
+        if tuple(out.shape) != (N, H, W, 8):
+            raise PmnError("stem: bad `out` shape")
+    with torch.cuda.device(img.device):
+        check(_lib.lib().pmn_stem(img.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1.data_ptr(), s1.data_ptr(), out.data_ptr(),
+                                  N, H, W, _stream(img)), "pmn_stem")
+    return out
