@@ -435,17 +435,16 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             }
             __syncthreads();
         }
-        // item role: this view's similarities of my items
-        float x[NIT][G];
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const int d = min(dA0 + j * DSTEP, D - 1);
-#pragma unroll
-            for (int g = 0; g < G; ++g) x[j][g] = simt[g * SS + d * NPIX + pixA];
-        }
+        // item role: this view's similarities of my items (re-read from the LDS tile in chunks of NI to keep few live)
         if (MODE == MODE_NEIGHBOR) {
             if (!okA) return;
-            float o[NIT];
+            float x[NIT][G], o[NIT];
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                const int d = min(dA0 + j * DSTEP, D - 1);
+#pragma unroll
+                for (int g = 0; g < G; ++g) x[j][g] = simt[g * SS + d * NPIX + pixA];
+            }
             mlp_items<G, NIT, NI>(wlds_a, x, o);
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
@@ -456,16 +455,25 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         }
         // PixelwiseNet + max over D (first arg-max on ties through the ~d low word)
         {
-            float r[NIT];
-            mlp_items<G, NIT, NI>(wlds_b, x, r);
             unsigned long long best = 0ull;
 #pragma unroll
-            for (int j = 0; j < NIT; ++j) {
-                const int d = dA0 + j * DSTEP;
-                if (d < D) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(pmn_sigmoid(r[j])) << 32) |
-                                                   (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
-                    best = key > best ? key : best;
+            for (int c = 0; c < NIT / NI; ++c) {
+                float xc[NI][G], r[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                }
+                mlp_from_lds<G, NI>(wlds_b, xc, r);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int d = dA0 + (c * NI + i) * DSTEP;
+                    if (d < D) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(pmn_sigmoid(r[i])) << 32) |
+                                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
+                        best = key > best ? key : best;
+                    }
                 }
             }
             atomicMax(&vwkey[pixA], best);
@@ -474,9 +482,11 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         const unsigned long long key = vwkey[pixA];
         const float vwp = __uint_as_float((unsigned)(key >> 32));
 #pragma unroll
-        for (int j = 0; j < NIT; ++j)
+        for (int j = 0; j < NIT; ++j) {
+            const int d = min(dA0 + j * DSTEP, D - 1);
 #pragma unroll
-            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], x[j][g], vwp);
+            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], simt[g * SS + d * NPIX + pixA], vwp);
+        }
         wsum += vwp;
         if (tid < NPIX && okA) {
             const size_t o = ((size_t)b * N + v) * hw + pA;
