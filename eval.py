@@ -12,6 +12,7 @@ path); with several processes the reference views are sharded round-robin across
 and each scan's maps are all-gathered over RCCL for the fusion step, which runs on the device instead of in numpy/cv2.
 """
 import argparse
+import collections
 import os
 import sys
 import time
@@ -60,12 +61,32 @@ def save_depth(args, rank, world, device):
     loader = DataLoader(dataset=dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
                         drop_last=False)
     produced = {}  # (scan, ref view) -> [2,H,W] on device, kept for the per-scan gather
+    # Per-scan feature cache: every image of a scan is a source view of ~num_views other samples, and
+    # the reference re-encodes it each time.  Feature pyramids (53 MB per 1600x1200 view, channels-last, on the device) are
+    # kept per (scan, light, view) in an LRU of --feature_cache entries; only the views missing from it go through FeatureNet.
+    cache = collections.OrderedDict()
+    use_cache = args.feature_cache > 0 and args.batch_size == 1
     with torch.no_grad():
         for batch_idx, sample in enumerate(loader):
             start = time.time()
             images = [im.to(device) for im in sample["images"]]
+            features = None
+            if use_cache and all(im.shape == images[0].shape for im in images) and \
+                    images[0].shape[2] % 8 == 0 and images[0].shape[3] % 8 == 0:
+                keys = [(sample["scan"][0], sample["light"][0], int(v), tuple(images[0].shape[2:]))
+                        for v in sample["view_ids"][0]]
+                missing = [i for i, k in enumerate(keys) if k not in cache]
+                if missing:
+                    f = model.feature.forward_hip([images[i] for i in missing])
+                    for j, i in enumerate(missing):
+                        cache[keys[i]] = {s: t[j:j + 1] for s, t in f.items()}
+                for k in keys:
+                    cache.move_to_end(k)
+                features = [{s: t.permute(0, 3, 1, 2) for s, t in cache[k].items()} for k in keys]
+                while len(cache) > args.feature_cache:
+                    cache.popitem(last=False)
             depth, confidence, _ = model(images, sample["intrinsics"].to(device), sample["extrinsics"].to(device),
-                                         sample["depth_min"].to(device), sample["depth_max"].to(device))
+                                         sample["depth_min"].to(device), sample["depth_max"].to(device), features=features)
             depth_np = depth.detach().cpu().numpy()
             conf_np = confidence.detach().cpu().numpy()
             print("Iter {}/{}, time = {:.3f}".format(batch_idx + 1, len(loader), time.time() - start))
@@ -157,6 +178,9 @@ def build_parser():
     p.add_argument("--photo_thres", type=float, default=0.5, help="threshold for photometric consistency filtering")
     # additions
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader worker processes per rank")
+    p.add_argument("--feature_cache", type=int, default=64,
+                   help="views whose FeatureNet pyramids stay cached on the device per rank (0 = re-encode every sample "
+                        "like the reference; needs --batch_size 1)")
     return p
 
 

@@ -64,4 +64,5 @@ class MVSDataset(Dataset):
                 depth_min, depth_max = depth_params[0], depth_params[1]
         return {"images": images, "intrinsics": np.stack(intrinsics), "extrinsics": np.stack(extrinsics),
                 "depth_min": depth_min, "depth_max": depth_max, "ref_view": view_ids[0],
+                "view_ids": np.asarray(view_ids, np.int64), "scan": scan, "light": light,
                 "filename": os.path.join(scan, "{}", "{:0>8}".format(view_ids[0]) + "{}")}

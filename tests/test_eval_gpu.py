@@ -53,4 +53,15 @@ def test_eval_cli_end_to_end(tmp_path):
                                torch.tensor([s["depth_min"]]).cuda(), torch.tensor([s["depth_max"]]).cuda())
     got = data_io.read_map(os.path.join(out, "scan9", "depth_est", "00000000.pfm"))[..., 0]
     np.testing.assert_array_equal(got, depth[0, 0].cpu().numpy())
+    # the per-scan feature cache must not change a single bit: rerun without it and compare every written map
+    out2 = str(tmp_path / "out_nocache")
+    torch.manual_seed(3)
+    pm_eval.main(["--input_folder", data, "--output_folder", out2, "--checkpoint_path", ckpt, "--scan_list",
+                  os.path.join(data, "list.txt"), "--num_views", "2", "--output_type", "depth", "--num_workers", "0",
+                  "--feature_cache", "0"])
+    for v in range(4):
+        for kind in ("depth_est", "confidence"):
+            a = data_io.read_map(os.path.join(out, "scan9", kind, "{:0>8}.pfm".format(v)))
+            b = data_io.read_map(os.path.join(out2, "scan9", kind, "{:0>8}.pfm".format(v)))
+            np.testing.assert_array_equal(a, b)
     assert float(depth.min()) >= 425.0 * 0.9 and float(depth.max()) <= 935.0 * 1.1
