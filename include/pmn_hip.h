@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 3
+#define PMN_ABI_VERSION 4
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -125,6 +125,18 @@ int pmn_conv2d(const float *in, const float *weights, const float *shift, const 
  * w_out [64][16] in pack_conv layout (device) -> out [N,H,W,16]. */
 int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float *b_in, const float *w_out, float *out,
                  int N, int H, int W, int cin, int cmid, int cout, void *stream);
+
+/* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
+ * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as
+ *   out[c] = bilinear_x2(u)[c] + b[c] + sum_ci x[ci] * w[ci][c]
+ * with w = output . inner and b = output . bias_inner formed in float64 on the host (patchmatchnet_amd/params.py: fold_fpn):
+ *   1/8:  [feature3 | u8] = W8 conv10          (cin 64, cout 112, ca 64, u = NULL)
+ *   1/4:  [feature2 | u4] = up(u8) + W4 conv7   (cin 32, cout 48,  ca 32)
+ *   1/2:   feature1       = up(u4) + W2 conv4   (cin 16, cout 16,  ca 16)
+ * x [N,H,W,cin]; u [N,H/2,W/2,cout] or NULL; w DEVICE float [cin][cout]; b DEVICE float [cout]; channels [0,ca) go to
+ * out_a [N,H,W,ca], the remaining cout-ca to out_b [N,H,W,cout-ca] (NULL when ca == cout). */
+int pmn_fpn_level(const float *x, const float *u, const float *w, const float *b, float *out_a, float *out_b, int N, int H,
+                  int W, int cin, int cout, int ca, void *stream);
 
 /* ConvTranspose2d(8, 8, k=3, stride=2, padding=1, output_padding=1, bias=False) + BatchNorm + ReLU of the Refinement net
  * (reference models/net.py:86-88, 114).  in [N,Hi,Wi,8]; weights DEVICE float [3][3][8][8] ([ky][kx][ci][co], BatchNorm scale

@@ -522,6 +522,142 @@ extern "C" int pmn_fpn_tail(const float* x, const float* up, const float* w_in, 
     return PMN_OK;
 }
 
+// ---- one level of the FOLDED FPN head ------------------------------------------------------------------------------------
+// The FPN head (reference models/net.py:57-67) has no non-linearity: output_k(upsample(intra) + inner_k(conv)) distributes
+// over the sum, and a 1x1 convolution commutes with bilinear up-sampling (its taps sum to 1, so biases pass through).  With
+//   W8 = [output1; output2; output3]            (112 x 64, applied to conv10 at 1/8)
+//   W4 = [output2; output3] . inner1, b4 = [output2; output3] . b_inner1      (48 x 32, applied to conv7 at 1/4)
+//   W2 = output3 . inner2,            b2 = output3 . b_inner2                 (16 x 16, applied to conv4 at 1/2)
+// (products formed in fp64 on the host, params.fold_fpn) the three feature maps are
+//   [f3 | u] = W8 conv10        [f2 | t] = up2(u) + W4 conv7 + b4        f1 = up2(t) + W2 conv4 + b2
+// and the 64-channel intermediates (184 MB at 1/4 and 737 MB at 1/2 for six 1600x1200 views) never exist.  One kernel per
+// level: out[c] = up2(u)[c] + b[c] + sum_ci x[ci] w[ci][c]; channels [0,CA) go to outA, the rest to outB.  A workgroup owns
+// 16x16 pixels, stages x and the 10x10 patch of u it samples in LDS with coalesced float4 loads, then every thread
+// produces its pixel 16 channels at a time from ds_read_b128's and wave-uniform SGPR weights.
+template <int CIN, int COUT, int CA, bool UP>
+__global__ __launch_bounds__(PMN_BLOCK, 2) void fpn_level_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                               const float* __restrict__ wgt,
+                                                               const float* __restrict__ bias, float* __restrict__ outA,
+                                                               float* __restrict__ outB, int N, int H, int W) {
+    constexpr int TW = 16, TH = 16, XP = CIN + 4, UPW = 10, UPP = COUT + 4, CB = COUT - CA;
+    static_assert(CIN % 4 == 0 && COUT % 16 == 0 && CA % 16 == 0, "channel tiling");
+    extern __shared__ float4 fl_lds4[];
+    float* xs = reinterpret_cast<float*>(fl_lds4);
+    float* us = xs + TW * TH * XP;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* wt = (const cfloat*)wgt;  // [CIN][COUT]
+    const cfloat* bs = (const cfloat*)bias;  // [COUT]
+    const int tid = threadIdx.x, tx = tid % TW, ty = tid / TW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int uh = H / 2, uw = W / 2;
+    const int uy_base = max(oy0 / 2 - 1, 0), ux_base = max(ox0 / 2 - 1, 0);
+
+    for (int idx = tid; idx < TW * TH * (CIN / 4); idx += PMN_BLOCK) {
+        const int pix = idx / (CIN / 4), q = idx - pix * (CIN / 4);
+        const int gy = min(oy0 + pix / TW, H - 1), gx = min(ox0 + pix % TW, W - 1);
+        *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) =
+            *reinterpret_cast<const float4*>(x + (((size_t)n * H + gy) * W + gx) * CIN + 4 * q);
+    }
+    if constexpr (UP) {
+        for (int idx = tid; idx < UPW * UPW * (COUT / 4); idx += PMN_BLOCK) {
+            const int pix = idx / (COUT / 4), q = idx - pix * (COUT / 4);
+            const int gy = min(uy_base + pix / UPW, uh - 1), gx = min(ux_base + pix % UPW, uw - 1);
+            *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) =
+                *reinterpret_cast<const float4*>(u + (((size_t)n * uh + gy) * uw + gx) * COUT + 4 * q);
+        }
+    }
+    __syncthreads();
+
+    const int oy = min(oy0 + ty, H - 1), ox = min(ox0 + tx, W - 1);
+    const bool live = oy0 + ty < H && ox0 + tx < W;
+    int uy0 = 0, uy1 = 0, ux0 = 0, ux1 = 0;
+    float ly = 0.f, lx = 0.f;
+    if constexpr (UP) {
+        up2_taps(oy, uh, uy0, uy1, ly);
+        up2_taps(ox, uw, ux0, ux1, lx);
+    }
+    const float* u00 = us + ((uy0 - uy_base) * UPW + (ux0 - ux_base)) * UPP;
+    const float* u01 = us + ((uy0 - uy_base) * UPW + (ux1 - ux_base)) * UPP;
+    const float* u10 = us + ((uy1 - uy_base) * UPW + (ux0 - ux_base)) * UPP;
+    const float* u11 = us + ((uy1 - uy_base) * UPW + (ux1 - ux_base)) * UPP;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const float* xp = xs + tid * XP;
+    const size_t opix = ((size_t)n * H + oy) * W + ox;
+
+#pragma unroll 1
+    for (int c0 = 0; c0 < COUT; c0 += 16) {
+        float acc[16];
+        if constexpr (UP) {
+#pragma unroll
+            for (int c = 0; c < 16; c += 4) {
+                const float4 p00 = *reinterpret_cast<const float4*>(u00 + c0 + c), p01 = *reinterpret_cast<const float4*>(u01 + c0 + c);
+                const float4 p10 = *reinterpret_cast<const float4*>(u10 + c0 + c), p11 = *reinterpret_cast<const float4*>(u11 + c0 + c);
+                // ATen upsample_bilinear2d: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)
+                acc[c] = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+                acc[c + 1] = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+                acc[c + 2] = hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z);
+                acc[c + 3] = hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w);
+            }
+            const cfloat* bq = bs + __builtin_amdgcn_readfirstlane(c0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += bq[c];
+        } else {
+            const cfloat* bq = bs + __builtin_amdgcn_readfirstlane(c0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = bq[c];
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(xp + ci);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(ci * COUT + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(v[k], wq[k * COUT + c], acc[c]);
+            __builtin_amdgcn_sched_barrier(0);  // one 64-weight batch in SGPRs at a time
+        }
+        if (live) {
+            float* o = (CB == 0 || c0 < CA) ? outA + opix * CA + c0 : outB + opix * (CB > 0 ? CB : 1) + (c0 - CA);
+#pragma unroll
+            for (int c = 0; c < 16; c += 4)
+                *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+        }
+    }
+}
+
+template <int CIN, int COUT, int CA, bool UP>
+static int launch_fpn_level(const float* x, const float* u, const float* w, const float* b, float* outA, float* outB, int N,
+                            int H, int W, hipStream_t st) {
+    const size_t lds = (size_t)(16 * 16 * (CIN + 4) + (UP ? 10 * 10 * (COUT + 4) : 0)) * sizeof(float);
+    auto kern = fpn_level_kernel<CIN, COUT, CA, UP>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return PMN_ERR_LAUNCH;
+    const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(PMN_BLOCK), lds, st, x, u, w, b, outA, outB, N, H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// x [N,H,W,cin]; u [N,H/2,W/2,cout] or NULL (no up-sampled term); w [cin][cout], b [cout] (params.fold_fpn);
+// out_a [N,H,W,ca] receives channels [0,ca), out_b [N,H,W,cout-ca] the rest (NULL when ca == cout).
+extern "C" int pmn_fpn_level(const float* x, const float* u, const float* w, const float* b, float* out_a, float* out_b,
+                             int N, int H, int W, int cin, int cout, int ca, void* stream) {
+    if (!x || !w || !b || !out_a || N < 1 || H < 1 || W < 1 || ca < 1 || ca > cout) return PMN_ERR_ARG;
+    if ((ca < cout) != (out_b != nullptr)) return PMN_ERR_ARG;
+    if (u && ((H & 1) || (W & 1))) return PMN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!u && cin == 64 && cout == 112 && ca == 64) return launch_fpn_level<64, 112, 64, false>(x, u, w, b, out_a, out_b, N, H, W, st);
+    if (u && cin == 32 && cout == 48 && ca == 32) return launch_fpn_level<32, 48, 32, true>(x, u, w, b, out_a, out_b, N, H, W, st);
+    if (u && cin == 16 && cout == 16 && ca == 16) return launch_fpn_level<16, 16, 16, true>(x, u, w, b, out_a, out_b, N, H, W, st);
+    return PMN_ERR_SHAPE;
+}
+
 // ---- ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1) + folded BatchNorm + ReLU (Refinement, net.py:86-88,114) ----
 // out[oy,ox,co] = sum_{ky,kx,ci} in[(oy+1-ky)/2, (ox+1-kx)/2, ci] * w[ky][kx][ci][co] over the (ky,kx) for which both
 // source coordinates are integral and in range: one tap for even coordinates (k=1), two for odd ones (k=0 and k=2).

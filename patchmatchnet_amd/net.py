@@ -35,6 +35,7 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+        self.fold_fpn = True  # forward_hip: composed 1x1 convolutions (False = layer by layer, as the reference orders them)
 
     # ---- HIP execution (pmn_conv2d): same parameters, channels-last activations, BN/ReLU/FPN-add fused ----------------
     _SPEC = [(3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1),
@@ -56,6 +57,10 @@ class FeatureNet(nn.Module):
                 m = getattr(self, name)
                 w, s = params.pack_conv(m.weight, bias=m.bias)
                 pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            fold = params.fold_fpn(self.output1.weight, self.inner1.weight, self.inner1.bias, self.inner2.weight,
+                                   self.inner2.bias, self.output2.weight, self.output3.weight)
+            for lvl, (w, b) in fold.items():
+                pk[f"fpn{lvl}"] = (torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -78,6 +83,13 @@ class FeatureNet(nn.Module):
             if i in (4, 7, 10):
                 feats[i] = t
         half, quarter, eighth = feats[4], feats[7], feats[10]
+        if self.fold_fpn:
+            # the FPN head is linear: its 1x1 convolutions are composed on the host (params.fold_fpn) and each level is one
+            # bandwidth-bound kernel -- the 64-channel intermediates at 1/4 and 1/2 resolution never exist
+            f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)
+            f2, u4 = ops.fpn_level(quarter, u8, *pk["fpn4"], ca=32)
+            f1, _ = ops.fpn_level(half, u4, *pk["fpn2"], ca=16)
+            return {3: f3, 2: f2, 1: f1}
         out = {3: ops.conv2d(eighth, *pk["output1"], 64, 1)}
         top = ops.conv2d(quarter, *pk["inner1"], 64, 1, up=eighth)       # upsample(conv10) + inner1(conv7)
         out[2] = ops.conv2d(top, *pk["output2"], 32, 1)

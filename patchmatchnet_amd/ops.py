@@ -349,6 +349,28 @@ def fpn_tail(x: torch.Tensor, up: torch.Tensor, w_in: torch.Tensor, b_in: torch.
     return out
 
 
+def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, ca: int):
+    """pmn_fpn_level: one level of the folded FPN head, out = bilinear_x2(u) + b + x @ w (reference models/net.py:57-67 with
+    the 1x1 convolutions composed, params.fold_fpn).  x [N,H,W,cin], u [N,H/2,W/2,cout] or None, w [cin,cout], b [cout]
+    -> (out_a [N,H,W,ca], out_b [N,H,W,cout-ca] or None)."""
+    for n_, t_ in (("x", x), ("w", w), ("b", b)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    cout = w.shape[1]
+    if tuple(w.shape) != (cin, cout) or tuple(b.shape) != (cout,) or not 0 < ca <= cout:
+        raise PmnError("fpn_level: inconsistent shapes")
+    if u is not None:
+        _dev(u, "u")
+        if tuple(u.shape) != (N, H // 2, W // 2, cout) or H % 2 or W % 2:
+            raise PmnError("fpn_level: `u` must be [N,H/2,W/2,cout]")
+    out_a = torch.empty((N, H, W, ca), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((N, H, W, cout - ca), dtype=torch.float32, device=x.device) if ca < cout else None
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_fpn_level(x.data_ptr(), _ptr(u), w.data_ptr(), b.data_ptr(), out_a.data_ptr(), _ptr(out_b),
+                                       N, H, W, cin, cout, ca, _stream(x)), "pmn_fpn_level")
+    return out_a, out_b
+
+
 def deconv3x3s2(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """pmn_deconv3x3s2: ConvTranspose2d(k3,s2,p1,op1) + folded BN + ReLU; x [N,Hi,Wi,8] -> [N,2Hi,2Wi,8]."""
     _dev(x, "x")

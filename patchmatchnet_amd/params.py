@@ -104,6 +104,23 @@ def pack_conv(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
     return np.ascontiguousarray(wp.astype(np.float32)), np.ascontiguousarray(sp.astype(np.float32))
 
 
+def fold_fpn(output1, inner1, b_inner1, inner2, b_inner2, output2, output3):
+    """FeatureNet's FPN head (reference models/net.py:57-67) is linear, so its 1x1 convolutions compose (float64 here):
+        [f3 | u8] = W8 conv10,   [f2 | u4] = up(u8) + W4 conv7 + b4,   f1 = up(u4) + W2 conv4 + b2
+    with W8 = [output1; output2; output3], W4 = [output2; output3] @ inner1, W2 = output3 @ inner2 (biases alike; a 1x1
+    convolution commutes with bilinear up-sampling because the taps sum to one).  Arguments are the Conv2d weights
+    [cout,cin,1,1] / biases; returns {8: (w [64,112], b [112]), 4: (w [32,48], b [48]), 2: (w [16,16], b [16])} as float32
+    arrays in the [cin][cout] layout pmn_fpn_level reads."""
+    O1, I1, I2, O2, O3 = (_np64(t)[:, :, 0, 0] for t in (output1, inner1, inner2, output2, output3))
+    b1, b2 = _np64(b_inner1), _np64(b_inner2)
+    O23 = np.concatenate([O2, O3], 0)  # [48,64]
+    W8 = np.concatenate([O1, O23], 0)  # [112,64]
+    W4, b4 = O23 @ I1, O23 @ b1        # [48,32], [48]
+    W2, bb2 = O3 @ I2, O3 @ b2         # [16,16], [16]
+    f = lambda a: np.ascontiguousarray(a.astype(np.float32))
+    return {8: (f(W8.T), np.zeros(W8.shape[0], np.float32)), 4: (f(W4.T), f(b4)), 2: (f(W2.T), f(bb2))}
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

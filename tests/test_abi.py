@@ -138,3 +138,30 @@ def test_conv_packing_layouts():
     wdp, sdp = PP.pack_deconv(wd, bn=bn)
     assert wdp.shape == (3, 3, 8, 8)
     np.testing.assert_allclose(wdp[2, 1, 3], (wd[3, :, 2, 1].double() * scale).float().numpy(), rtol=1e-6)
+
+
+def test_fold_fpn_is_the_reference_head():
+    """params.fold_fpn: the composed 1x1 convolutions reproduce FeatureNet's FPN head (reference models/net.py:57-67) --
+    checked in float64 torch against the layer-by-layer head of the module itself."""
+    import torch.nn.functional as F
+    from patchmatchnet_amd import params as PR
+    from patchmatchnet_amd.net import FeatureNet
+    torch.manual_seed(5)
+    net = FeatureNet().double().eval()
+    c4, c7, c10 = torch.randn(2, 16, 12, 16).double(), torch.randn(2, 32, 6, 8).double(), torch.randn(2, 64, 3, 4).double()
+    up = lambda x: F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
+    with torch.no_grad():
+        ref3 = net.output1(c10)
+        top = up(c10) + net.inner1(c7)
+        ref2 = net.output2(top)
+        ref1 = net.output3(up(top) + net.inner2(c4))
+    fold = PR.fold_fpn(net.output1.weight, net.inner1.weight, net.inner1.bias, net.inner2.weight, net.inner2.bias,
+                       net.output2.weight, net.output3.weight)
+    assert fold[8][0].shape == (64, 112) and fold[4][0].shape == (32, 48) and fold[2][0].shape == (16, 16)
+    lin = lambda x, wb: torch.einsum("bchw,cd->bdhw", x, torch.from_numpy(wb[0]).double()) + \
+        torch.from_numpy(wb[1]).double()[None, :, None, None]
+    l8 = lin(c10, fold[8])
+    l4 = up(l8[:, 64:]) + lin(c7, fold[4])
+    l2 = up(l4[:, 32:]) + lin(c4, fold[2])
+    for got, ref in ((l8[:, :64], ref3), (l4[:, :32], ref2), (l2, ref1)):
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6

@@ -256,11 +256,14 @@ def test_conv2d_against_torch(cin, cout, K, stride, pad, dil, in_nchw, out_nchw,
     assert err < 2e-5, err
 
 
-def test_featurenet_hip_matches_miopen():
-    """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels."""
+@pytest.mark.parametrize("fold", [True, False])
+def test_featurenet_hip_matches_miopen(fold):
+    """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels, with the FPN
+    head's 1x1 convolutions composed (pmn_fpn_level, the default) and layer by layer."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
+    model.feature.fold_fpn = fold
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
