@@ -202,14 +202,24 @@ __global__ __launch_bounds__(PMN_BLOCK, 4) void conv_tiled_kernel(const float* _
     for (int cc0 = 0; cc0 < CIN; cc0 += CC) {
         if (cc0) __syncthreads();
         // stage: ih x iw pixels x CC channels
-        for (int idx = tid; idx < ih * iw * CQ; idx += PMN_BLOCK) {
-            const int pix = idx / CQ, q = idx - pix * CQ;
-            const int r = pix / iw, c = pix - r * iw;
-            const int gy = iy0 + r, gx = ix0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                v = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + cc0 + 4 * q);
-            *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v;
+        // batches of SB loads per thread in flight (one load per trip exposes a full memory round trip per 16 bytes)
+        constexpr int SB = 4;
+        for (int base = tid; base < ih * iw * CQ; base += PMN_BLOCK * SB) {
+            float4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * PMN_BLOCK, pix = idx / CQ, q = idx - pix * CQ;
+                const int r = pix / iw, c = pix - r * iw;
+                const int gy = iy0 + r, gx = ix0 + c;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < ih * iw * CQ && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v[u] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + cc0 + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * PMN_BLOCK, pix = idx / CQ, q = idx - pix * CQ;
+                if (idx < ih * iw * CQ) *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v[u];
+            }
         }
         __syncthreads();
 #pragma unroll 1

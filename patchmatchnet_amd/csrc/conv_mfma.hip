@@ -1,0 +1,185 @@
+// conv_mfma.hip -- fp32 implicit-GEMM convolution on the matrix cores for FeatureNet's wide layers (reference
+// models/net.py:25-34: conv5..conv10, 16/32/64 channels), conv + folded BatchNorm shift + ReLU, channels-last in and out.
+//
+// Why: the VALU kernel of conv.hip feeds every FMA a wave-uniform SGPR weight.  From 32x32x3x3 weights up the filter bank no
+// longer fits the 16 KB scalar cache, each 64-weight batch is an L2 round trip, and the layers run at 43-75 TFLOP/s
+// (profiles/r01_final_*).  v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise a k-ordered fmaf chain) at the same 157 TFLOP/s
+// peak, takes ONE VGPR per operand per lane and leaves the scalar path out of the loop.
+//
+// GEMM view: rows = output pixels, columns = output channels, k = (tap, input channel).
+//   workgroup  NW waves, a TH x 16 tile of output pixels (TH = 2*PG*NW rows), all COUT channels
+//   wave       PG groups of 32 pixels (2 tile rows) x NT = COUT/32 column blocks -> PG*NT accumulators of 16 VGPRs
+//   A operand  the (TH*S + K-1) x (16*S + K-1) x CC input patch staged in LDS (zero-filled outside the image); lane
+//              (i = lane&31, h = lane>>5) reads ONE ds_read_b128 = channels [8*c8 + 4h, +4) of its pixel at the current tap
+//   B operand  weights repacked on the host (params.pack_conv_mfma) as [tap][cin/8][NT][64 lanes][4]: a wave's
+//              global_load_dwordx4 is one contiguous 1 KB line set, shared by every wave on the chip (L1/L2 resident)
+//   k-step j   (0..3) multiplies A.j by B.j: k pairs (cin 8*c8+j, cin 8*c8+4+j) -- any k order is valid as long as A and B
+//              agree, and the sum stays a plain fp32 fmaf chain.
+// C/D layout of the 32x32 MFMA: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5): for a fixed register
+// the 32 lanes of a half-wave store 32 consecutive output channels of one pixel (128 contiguous bytes).
+#include "pmn_common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MfmaConvArgs {
+    int N, H, W, Ho, Wo, pad, relu;
+};
+
+template <int CIN, int CC, int COUT, int K, int S, int NW, int PG, int D>
+__global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __restrict__ in, const float4* __restrict__ wB,
+                                                          const float* __restrict__ shift, float* __restrict__ out,
+                                                          const MfmaConvArgs a) {
+    constexpr int TW = 16, TH = 2 * PG * NW, NT = COUT / 32, C8 = CC / 8, CCP = CC + 4, CQ = CC / 4, NTHR = 64 * NW;
+    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
+    constexpr int STEPS = K * K * C8;  // k-steps of 8 input channels per staged chunk: (tap, c8) flattened, c8 fastest
+    constexpr int SB = 4;              // staging loads in flight per thread
+    static_assert(CIN % CC == 0 && CC % 8 == 0 && COUT % 32 == 0 && STEPS % D == 0, "channel tiling");
+    extern __shared__ float4 mf_lds4[];
+    float* tile = reinterpret_cast<float*>(mf_lds4);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, li = lane & 31;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+
+    f32x16 acc[PG][NT];
+#pragma unroll
+    for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][t][r] = 0.0f;
+
+    // A-side LDS offsets (words) of this lane's pixel in each pixel group, tap (0,0), first channel chunk
+    int aoff[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const int ty = (wave * PG + g) * 2 + (li >> 4), tx = li & 15;
+        aoff[g] = (ty * S * IW + tx * S) * CCP + 4 * h;
+    }
+
+    // B operands run D k-steps (D x 16*PG*NT/2... MFMA issue slots) ahead of their use in a register ring: the loads are L2
+    // round trips (every wave streams the whole filter bank), far longer than the 4*PG*NT MFMAs of one step
+    float4 bq[D][NT];
+    const float4* bl = wB + lane;
+    auto b_index = [&](int s, int cc0) { return ((s / C8) * (CIN / 8) + cc0 / 8 + (s % C8)) * NT * 64; };
+
+#pragma unroll 1
+    for (int cc0 = 0; cc0 < CIN; cc0 += CC) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bq[d][t] = bl[b_index(d, cc0) + t * 64];
+        if (cc0) __syncthreads();
+        // staging in batches of SB loads per thread: one load per trip would expose a full HBM/L2 round trip per 16 bytes
+        for (int base = tid; base < IH * IW * CQ; base += NTHR * SB) {
+            float4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * NTHR, pix = idx / CQ, q = idx - pix * CQ;
+                const int r = pix / IW, c = pix - r * IW;
+                const int gy = iy0 + r, gx = ix0 + c;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < IH * IW * CQ && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v[u] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + cc0 + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * NTHR, pix = idx / CQ, q = idx - pix * CQ;
+                if (idx < IH * IW * CQ) *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v[u];
+            }
+        }
+        __syncthreads();
+        // B operands run D-1 steps ahead in a D-deep register ring (L2 latency); A operands one step ahead inside a group of D
+        // steps (ds_read latency).  A ring slot is re-loaded only AFTER the MFMAs that read it have issued (no copies, the
+        // registers stay put across the back-edge); sched_barriers pin that order -- unfenced, hipcc sinks the loads to the
+        // end of the group and waits for all of them
+        auto a_offset = [&](int s) { return (((s / C8) / K) * IW + (s / C8) % K) * CCP + 8 * (s % C8); };
+#pragma unroll 1
+        for (int s0 = 0; s0 < STEPS; s0 += D) {
+            float4 ar[2][PG];
+#pragma unroll
+            for (int g = 0; g < PG; ++g) ar[0][g] = *reinterpret_cast<const float4*>(tile + aoff[g] + a_offset(s0));
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int s = s0 + d;
+                if (d + 1 < D) {
+#pragma unroll
+                    for (int g = 0; g < PG; ++g)
+                        ar[(d + 1) & 1][g] = *reinterpret_cast<const float4*>(tile + aoff[g] + a_offset(s + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int g = 0; g < PG; ++g) {
+                        const float4 a4 = ar[d & 1][g];
+                        const float af = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float4 b4 = bq[d][t];
+                            const float bf = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[g][t], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int sp = min(s + D, STEPS - 1);  // the last D steps re-load the final step: no branch, no overrun
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bq[d][t] = bl[b_index(sp, cc0) + t * 64];
+            }
+        }
+    }
+
+    // epilogue: + shift (folded BatchNorm), ReLU, channels-last store
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float sh = shift[t * 32 + li];
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // pixel index inside the group of 32
+                const int oy = oy0 + (wave * PG + g) * 2 + (row >> 4), ox = ox0 + (row & 15);
+                float v = acc[g][t][r] + sh;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + t * 32 + li] = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int CC, int COUT, int K, int S, int NW, int PG, int D>
+static int launch_mfma(const float* in, const float* w, const float* shift, float* out, MfmaConvArgs a, hipStream_t st) {
+    constexpr int TH = 2 * PG * NW, IW = 15 * S + K, IH = (TH - 1) * S + K;
+    const size_t lds = (size_t)IH * IW * (CC + 4) * sizeof(float);
+    auto kern = conv_mfma_kernel<CIN, CC, COUT, K, S, NW, PG, D>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return PMN_ERR_LAUNCH;
+    const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][cout/32][64][4] (params.pack_conv_mfma, BatchNorm scale
+// folded in); shift DEVICE float[cout]; out [N,Ho,Wo,cout] channels-last.  Supported (cin,cout,K,stride): (64,64,3,1),
+// (32,32,3,1), (32,64,5,2), (16,32,5,2); pad = K/2.
+extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const float* shift, float* out, int N, int H, int W,
+                               int cin, int cout, int K, int stride, int pad, int relu, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1 || pad < 0 || stride < 1) return PMN_ERR_ARG;
+    MfmaConvArgs a;
+    a.N = N; a.H = H; a.W = W; a.pad = pad; a.relu = relu;
+    a.Ho = (H + 2 * pad - K) / stride + 1;
+    a.Wo = (W + 2 * pad - K) / stride + 1;
+    if (a.Ho < 1 || a.Wo < 1) return PMN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 64 && cout == 64 && K == 3 && stride == 1) return launch_mfma<64, 32, 64, 3, 1, 2, 2, 4>(in, weights, shift, out, a, st);
+    if (cin == 32 && cout == 32 && K == 3 && stride == 1) return launch_mfma<32, 32, 32, 3, 1, 4, 2, 4>(in, weights, shift, out, a, st);
+    if (cin == 32 && cout == 64 && K == 5 && stride == 2) return launch_mfma<32, 8, 64, 5, 2, 2, 2, 5>(in, weights, shift, out, a, st);
+    if (cin == 16 && cout == 32 && K == 5 && stride == 2) return launch_mfma<16, 8, 32, 5, 2, 2, 2, 5>(in, weights, shift, out, a, st);
+    return PMN_ERR_SHAPE;
+}

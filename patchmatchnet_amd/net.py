@@ -35,6 +35,7 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+        self.mfma_convs = True  # forward_hip: conv5..conv10 on the fp32 matrix cores (False = VALU kernel for every layer)
         self.fold_fpn = True  # forward_hip: composed 1x1 convolutions (False = layer by layer, as the reference orders them)
 
     # ---- HIP execution (pmn_conv2d): same parameters, channels-last activations, BN/ReLU/FPN-add fused ----------------
@@ -53,6 +54,11 @@ class FeatureNet(nn.Module):
                 w, s = params.pack_conv(m.conv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                         eps=m.bn.eps)
                 pk[f"conv{i}"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                cv = m.conv
+                if (cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]) in ops.MFMA_CONV_SHAPES:
+                    w, s = params.pack_conv_mfma(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
+                                                 eps=m.bn.eps)
+                    pk[f"conv{i}_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             for name in ("output1", "inner1", "inner2", "output2", "output3"):
                 m = getattr(self, name)
                 w, s = params.pack_conv(m.weight, bias=m.bias)
@@ -78,8 +84,11 @@ class FeatureNet(nn.Module):
         for i, (k, s, p) in enumerate(self._SPEC):
             if i < 2:
                 continue
-            w, sh = pk[f"conv{i}"]
-            t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)
+            if self.mfma_convs and f"conv{i}_mfma" in pk:  # wide layers: implicit GEMM on the matrix cores
+                t = ops.conv2d_mfma(t, *pk[f"conv{i}_mfma"], k, s, p, relu=True)
+            else:
+                w, sh = pk[f"conv{i}"]
+                t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)
             if i in (4, 7, 10):
                 feats[i] = t
         half, quarter, eighth = feats[4], feats[7], feats[10]

@@ -349,6 +349,27 @@ def fpn_tail(x: torch.Tensor, up: torch.Tensor, w_in: torch.Tensor, b_in: torch.
     return out
 
 
+MFMA_CONV_SHAPES = {(64, 64, 3, 1), (32, 32, 3, 1), (32, 64, 5, 2), (16, 32, 5, 2)}  # (cin, cout, K, stride)
+
+
+def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: int, stride: int = 1, pad: int = 0,
+                relu: bool = True) -> torch.Tensor:
+    """pmn_conv2d_mfma: conv + folded-BN shift + ReLU as fp32 implicit GEMM on the matrix cores; x [N,H,W,cin] channels-last,
+    weights from params.pack_conv_mfma ([K*K, cin/8, cout/32, 64, 4]) -> [N,Ho,Wo,cout]."""
+    for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    cout = shift.shape[0]
+    if tuple(weights.shape) != (K * K, cin // 8, cout // 32, 64, 4):
+        raise PmnError("conv2d_mfma: weights are not in pack_conv_mfma layout for this input")
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    out = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d_mfma(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, H, W, cin,
+                                         cout, K, stride, pad, 1 if relu else 0, _stream(x)), "pmn_conv2d_mfma")
+    return out
+
+
 def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, ca: int):
     """pmn_fpn_level: one level of the folded FPN head, out = bilinear_x2(u) + b + x @ w (reference models/net.py:57-67 with
     the 1x1 convolutions composed, params.fold_fpn).  x [N,H,W,cin], u [N,H/2,W/2,cout] or None, w [cin,cout], b [cout]

@@ -121,6 +121,29 @@ def fold_fpn(output1, inner1, b_inner1, inner2, b_inner2, output2, output3):
     return {8: (f(W8.T), np.zeros(W8.shape[0], np.float32)), 4: (f(W4.T), f(b4)), 2: (f(W2.T), f(bb2))}
 
 
+def pack_conv_mfma(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
+    """Conv2d weight [cout,cin,K,K] (+ BatchNorm2d tensors or a conv bias) -> (float32 [K*K, cin/8, cout/32, 64, 4],
+    float32 [cout]) in the B-operand order of pmn_conv2d_mfma: lane (h = lane>>5, i = lane&31) of column block nt reads the four
+    weights w[nt*32 + i][8*c8 + 4*h + j][ky][kx], j = 0..3, as one 16-byte load.  BatchNorm folded in float64."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if cin % 8 or cout % 32:
+        raise ValueError("pack_conv_mfma: cin must be a multiple of 8 and cout a multiple of 32")
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        s = g / np.sqrt(v + eps)
+        w = w * s[:, None, None, None]
+        shift = b - m * s
+    elif bias is not None:
+        shift = _np64(bias)
+    else:
+        shift = np.zeros(cout)
+    # [cout, cin, ky, kx] -> [ky, kx, c8, h, j, nt, i] -> [tap, c8, nt, h, i, j]
+    t = w.transpose(2, 3, 1, 0).reshape(K * K, cin // 8, 2, 4, cout // 32, 32)
+    t = t.transpose(0, 1, 4, 2, 5, 3).reshape(K * K, cin // 8, cout // 32, 64, 4)
+    return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC passes over the conv layer micro-benchmark (scripts/conv_bench.py); counters only with --kernel-trace.
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv
+rm -rf $OUT; mkdir -p $OUT
+i=0
+while read -r line; do
+  [ -z "$line" ] && continue
+  i=$((i+1))
+  (cd /tmp && timeout 300 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/scripts/conv_bench.py > $OUT/p$i.log 2>&1)
+done <<LIST
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
+SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LEVEL_WAVES
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
+LIST
+python - <<'PY'
+import csv,glob,collections,os
+out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_conv'
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(out+'/p*/*counter_collection.csv')):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name']
+        if 'conv_' not in k: continue
+        agg[k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(out+'/summary.txt','w') as fo:
+    for key,cs in agg.items():
+        line='%s\n'%key + ''.join('   %-32s %16.0f (n=%d)\n'%(c, sum(v)/len(v), len(v)) for c,v in sorted(cs.items()))
+        print(line); fo.write(line)
+PY

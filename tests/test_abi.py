@@ -165,3 +165,17 @@ def test_fold_fpn_is_the_reference_head():
     l2 = up(l4[:, 32:]) + lin(c4, fold[2])
     for got, ref in ((l8[:, :64], ref3), (l4[:, :32], ref2), (l2, ref1)):
         assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def test_pack_conv_mfma_layout():
+    """params.pack_conv_mfma: lane (h, i) of column block nt holds w[nt*32+i][8*c8+4h+j][ky][kx] at [tap, c8, nt, 32h+i, j]."""
+    from patchmatchnet_amd import params as PR
+    w = torch.arange(64 * 32 * 5 * 5, dtype=torch.float32).reshape(64, 32, 5, 5)
+    p, s = PR.pack_conv_mfma(w)
+    assert p.shape == (25, 4, 2, 64, 4) and s.shape == (64,) and not s.any()
+    for (ky, kx, c8, nt, h, i, j) in [(0, 0, 0, 0, 0, 0, 0), (4, 3, 2, 1, 1, 17, 3), (2, 2, 3, 0, 0, 31, 1), (1, 4, 1, 1, 1, 0, 2)]:
+        assert p[ky * 5 + kx, c8, nt, 32 * h + i, j] == w[nt * 32 + i, 8 * c8 + 4 * h + j, ky, kx]
+    bn = (torch.full((64,), 2.0), torch.full((64,), 0.5), torch.full((64,), 0.25), torch.full((64,), 4.0 - 1e-5))
+    p2, s2 = PR.pack_conv_mfma(w, bn=bn)
+    np.testing.assert_allclose(p2, p, rtol=1e-6)          # scale = 2 / sqrt(4) = 1
+    np.testing.assert_allclose(s2, 0.5 - 0.25, rtol=1e-6)

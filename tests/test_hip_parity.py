@@ -256,6 +256,34 @@ def test_conv2d_against_torch(cin, cout, K, stride, pad, dil, in_nchw, out_nchw,
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("cin,cout,K,stride", [(64, 64, 3, 1), (32, 32, 3, 1), (32, 64, 5, 2), (16, 32, 5, 2)])
+@pytest.mark.parametrize("H,W", [(38, 54), (16, 16), (75, 100)])
+def test_conv2d_mfma_against_torch(cin, cout, K, stride, H, W):
+    """pmn_conv2d_mfma (fp32 implicit GEMM on the matrix cores) vs F.conv2d + BatchNorm + ReLU in float64, and vs the VALU
+    kernel pmn_conv2d on the same input; ragged tiles and borders."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin * 100 + cout + H)
+    N, pad = 2, K // 2
+    H, W = H * stride, W * stride
+    x = torch.randn(N, cin, H, W, generator=gen)
+    wt = 0.2 * torch.randn(cout, cin, K, K, generator=gen)
+    bn = (0.5 + torch.rand(cout, generator=gen), 0.1 * torch.randn(cout, generator=gen),
+          0.1 * torch.randn(cout, generator=gen), 0.5 + torch.rand(cout, generator=gen))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, pad)
+    ref = torch.relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                                    False, 0.0, 1e-5))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w, sh = PP.pack_conv_mfma(wt, bn=bn)
+    got = P.ops.conv2d_mfma(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), K, stride, pad, relu=True)
+    assert tuple(got.shape) == (N, ref.shape[2], ref.shape[3], cout)
+    err = float((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    w2, s2 = PP.pack_conv(wt, bn=bn)
+    valu = P.ops.conv2d(xin, torch.from_numpy(w2).to(DEV), torch.from_numpy(s2).to(DEV), cout, K, stride, pad, relu=True)
+    assert float((got - valu).abs().max() / ref.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_featurenet_hip_matches_miopen(fold):
     """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels, with the FPN
@@ -264,6 +292,7 @@ def test_featurenet_hip_matches_miopen(fold):
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
     model.feature.fold_fpn = fold
+    model.feature.mfma_convs = fold
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
