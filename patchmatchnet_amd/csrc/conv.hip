@@ -345,12 +345,24 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
     const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
     const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
 
-    for (int idx = tid; idx < 3 * IW * IW; idx += PMN_BLOCK) {
-        const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
-        const int gy = oy0 - 2 + r, gx = ox0 - 2 + q;
-        float v = 0.0f;
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
-        xin[(c * IW + r) * IWP + q] = v;
+    {   // all of a thread's patch loads in flight at once (one load per loop trip exposes a memory round trip per 4 bytes)
+        constexpr int NL = (3 * IW * IW + PMN_BLOCK - 1) / PMN_BLOCK;
+        float v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + u * PMN_BLOCK;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            const int gy = oy0 - 2 + r, gx = ox0 - 2 + q;
+            v[u] = 0.0f;
+            if (idx < 3 * IW * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v[u] = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + u * PMN_BLOCK;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            if (idx < 3 * IW * IW) xin[(c * IW + r) * IWP + q] = v[u];
+        }
     }
     __syncthreads();
     for (int m = tid; m < MW * MW; m += PMN_BLOCK) {
