@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 5
+#define PMN_ABI_VERSION 6
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -126,13 +126,18 @@ int pmn_conv2d(const float *in, const float *weights, const float *shift, const 
 int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float *b_in, const float *w_out, float *out,
                  int N, int H, int W, int cin, int cmid, int cout, void *stream);
 
-/* The same convolution (+ folded BatchNorm shift + ReLU) as fp32 implicit GEMM on the matrix cores
- * (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain) for FeatureNet's wide layers conv5..conv10
- * (reference models/net.py:25-34).  in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][cout/32][64][4]
- * (patchmatchnet_amd/params.py: pack_conv_mfma); shift DEVICE float[cout]; out [N,Ho,Wo,cout] channels-last.
- * Supported (cin,cout,K,stride): (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2). */
-int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int cin,
-                    int cout, int K, int stride, int pad, int relu, void *stream);
+/* The same convolution (+ folded BatchNorm shift / bias, optional ReLU) as fp32 implicit GEMM on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain).  in [N,H,W,cin] channels-last; weights DEVICE float
+ * [K*K][cin/8][coutp/32][64][4] with coutp = cout rounded up to 32 (patchmatchnet_amd/params.py: pack_conv_mfma); shift
+ * DEVICE float[coutp].
+ *   planar == 0  FeatureNet's wide layers conv5..conv10 (reference models/net.py:25-34): out [N,Ho,Wo,cout] channels-last,
+ *                out_b NULL, ca == cout, dil 1; supported (cin,cout,K,stride): (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2)
+ *   planar == 1  the offset heads propa_conv + eval_conv of one stage as ONE dilated 3x3 convolution over the reference feature
+ *                (models/patchmatch.py:288-311): channels [0,ca) -> out [N,ca,Ho,Wo], [ca,cout) -> out_b [N,cout-ca,Ho,Wo]
+ *                (NULL when ca == cout), both planar; K 3, stride 1, pad == dil; supported (cin,dil): (64,2), (32,4), (16,6),
+ *                cout <= 64 (other dilations: pmn_conv2d). */
+int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, float *out, float *out_b, int N, int H, int W,
+                    int cin, int cout, int ca, int K, int stride, int pad, int dil, int relu, int planar, void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

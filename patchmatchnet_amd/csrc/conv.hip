@@ -577,18 +577,30 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void fpn_level_kernel(const float* __
     const int uh = H / 2, uw = W / 2;
     const int uy_base = max(oy0 / 2 - 1, 0), ux_base = max(ox0 / 2 - 1, 0);
 
-    for (int idx = tid; idx < TW * TH * (CIN / 4); idx += PMN_BLOCK) {
-        const int pix = idx / (CIN / 4), q = idx - pix * (CIN / 4);
-        const int gy = min(oy0 + pix / TW, H - 1), gx = min(ox0 + pix % TW, W - 1);
-        *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) =
-            *reinterpret_cast<const float4*>(x + (((size_t)n * H + gy) * W + gx) * CIN + 4 * q);
-    }
-    if constexpr (UP) {
-        for (int idx = tid; idx < UPW * UPW * (COUT / 4); idx += PMN_BLOCK) {
-            const int pix = idx / (COUT / 4), q = idx - pix * (COUT / 4);
+    {   // every load of the tile in flight before the first LDS write (a load per loop trip exposes a memory round trip each)
+        constexpr int NX = CIN / 4, NU = UP ? (UPW * UPW * (COUT / 4) + PMN_BLOCK - 1) / PMN_BLOCK : 0;
+        float4 vx[NX], vu[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = tid + k * PMN_BLOCK, pix = idx / NX, q = idx - pix * NX;
+            const int gy = min(oy0 + pix / TW, H - 1), gx = min(ox0 + pix % TW, W - 1);
+            vx[k] = *reinterpret_cast<const float4*>(x + (((size_t)n * H + gy) * W + gx) * CIN + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int idx = min(tid + k * PMN_BLOCK, UPW * UPW * (COUT / 4) - 1), pix = idx / (COUT / 4), q = idx - pix * (COUT / 4);
             const int gy = min(uy_base + pix / UPW, uh - 1), gx = min(ux_base + pix % UPW, uw - 1);
-            *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) =
-                *reinterpret_cast<const float4*>(u + (((size_t)n * uh + gy) * uw + gx) * COUT + 4 * q);
+            vu[k] = *reinterpret_cast<const float4*>(u + (((size_t)n * uh + gy) * uw + gx) * COUT + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = tid + k * PMN_BLOCK, pix = idx / NX, q = idx - pix * NX;
+            *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) = vx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int idx = tid + k * PMN_BLOCK, pix = idx / (COUT / 4), q = idx - pix * (COUT / 4);
+            if (idx < UPW * UPW * (COUT / 4)) *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) = vu[k];
         }
     }
     __syncthreads();

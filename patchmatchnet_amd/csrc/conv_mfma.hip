@@ -22,15 +22,19 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct MfmaConvArgs {
-    int N, H, W, Ho, Wo, pad, relu;
+    int N, H, W, Ho, Wo, pad, relu, cout, ca;  // cout = real output channels (<= COUT), ca = channels that go to out (PLANAR)
 };
 
-template <int CIN, int CC, int COUT, int K, int S, int NW, int PG, int D>
+// PLANAR (the offset heads propa_conv / eval_conv, reference models/patchmatch.py:288-311, dilated 3x3, bias, no ReLU): the two
+// MFMA operands swap roles (rows = output channels, columns = pixels), so a register holds one output channel of 32
+// pixels = two 64-byte runs of a [B,cout,h,w] plane; channels [0,ca) go to `out`, [ca,cout) to `out_b` (both heads of a stage
+// are ONE convolution over the shared reference feature), channels >= cout are padding.
+template <int CIN, int CC, int COUT, int K, int S, int DIL, int NW, int PG, int D, bool PLANAR>
 __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __restrict__ in, const float4* __restrict__ wB,
                                                           const float* __restrict__ shift, float* __restrict__ out,
-                                                          const MfmaConvArgs a) {
+                                                          float* __restrict__ out_b, const MfmaConvArgs a) {
     constexpr int TW = 16, TH = 2 * PG * NW, NT = COUT / 32, C8 = CC / 8, CCP = CC + 4, CQ = CC / 4, NTHR = 64 * NW;
-    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
+    constexpr int IW = (TW - 1) * S + (K - 1) * DIL + 1, IH = (TH - 1) * S + (K - 1) * DIL + 1;
     constexpr int STEPS = K * K * C8;  // k-steps of 8 input channels per staged chunk: (tap, c8) flattened, c8 fastest
     constexpr int SB = 4;              // staging loads in flight per thread
     static_assert(CIN % CC == 0 && CC % 8 == 0 && COUT % 32 == 0 && STEPS % D == 0, "channel tiling");
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __re
         // steps (ds_read latency).  A ring slot is re-loaded only AFTER the MFMAs that read it have issued (no copies, the
         // registers stay put across the back-edge); sched_barriers pin that order -- unfenced, hipcc sinks the loads to the
         // end of the group and waits for all of them
-        auto a_offset = [&](int s) { return (((s / C8) / K) * IW + (s / C8) % K) * CCP + 8 * (s % C8); };
+        auto a_offset = [&](int s) { return ((((s / C8) / K) * IW + (s / C8) % K) * DIL) * CCP + 8 * (s % C8); };
 #pragma unroll 1
         for (int s0 = 0; s0 < STEPS; s0 += D) {
             float4 ar[2][PG];
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __re
                         for (int t = 0; t < NT; ++t) {
                             const float4 b4 = bq[d][t];
                             const float bf = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[g][t], 0, 0, 0);
+                            acc[g][t] = PLANAR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af, acc[g][t], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[g][t], 0, 0, 0);
                         }
                     }
                 }
@@ -132,54 +137,100 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __re
         }
     }
 
-    // epilogue: + shift (folded BatchNorm), ReLU, channels-last store
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float sh = shift[t * 32 + li];
+    // epilogue: + shift (folded BatchNorm / bias), ReLU, store
+    if constexpr (PLANAR) {
+        const int cb = a.cout - a.ca;
 #pragma unroll
         for (int g = 0; g < PG; ++g) {
+            const int oy = oy0 + (wave * PG + g) * 2 + (li >> 4), ox = ox0 + (li & 15);
+            const bool inside = oy < a.Ho && ox < a.Wo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // pixel index inside the group of 32
-                const int oy = oy0 + (wave * PG + g) * 2 + (row >> 4), ox = ox0 + (row & 15);
-                float v = acc[g][t][r] + sh;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + t * 32 + li] = v;
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (inside && co < a.cout) {
+                        float v = acc[g][t][r] + shift[co];
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        if (co < a.ca) out[(((size_t)n * a.ca + co) * a.Ho + oy) * a.Wo + ox] = v;
+                        else out_b[(((size_t)n * cb + (co - a.ca)) * a.Ho + oy) * a.Wo + ox] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float sh = shift[t * 32 + li];
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // pixel index inside the group of 32
+                    const int oy = oy0 + (wave * PG + g) * 2 + (row >> 4), ox = ox0 + (row & 15);
+                    float v = acc[g][t][r] + sh;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + t * 32 + li] = v;
+                }
             }
         }
     }
 }
 
-template <int CIN, int CC, int COUT, int K, int S, int NW, int PG, int D>
-static int launch_mfma(const float* in, const float* w, const float* shift, float* out, MfmaConvArgs a, hipStream_t st) {
-    constexpr int TH = 2 * PG * NW, IW = 15 * S + K, IH = (TH - 1) * S + K;
+template <int CIN, int CC, int COUT, int K, int S, int DIL, int NW, int PG, int D, bool PLANAR>
+static int launch_mfma(const float* in, const float* w, const float* shift, float* out, float* out_b, MfmaConvArgs a,
+                       hipStream_t st) {
+    constexpr int TH = 2 * PG * NW, IW = 15 * S + (K - 1) * DIL + 1, IH = (TH - 1) * S + (K - 1) * DIL + 1;
     const size_t lds = (size_t)IH * IW * (CC + 4) * sizeof(float);
-    auto kern = conv_mfma_kernel<CIN, CC, COUT, K, S, NW, PG, D>;
+    auto kern = conv_mfma_kernel<CIN, CC, COUT, K, S, DIL, NW, PG, D, PLANAR>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
         return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, out_b,
+                       a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
 
-// in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][cout/32][64][4] (params.pack_conv_mfma, BatchNorm scale
-// folded in); shift DEVICE float[cout]; out [N,Ho,Wo,cout] channels-last.  Supported (cin,cout,K,stride): (64,64,3,1),
-// (32,32,3,1), (32,64,5,2), (16,32,5,2); pad = K/2.
-extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const float* shift, float* out, int N, int H, int W,
-                               int cin, int cout, int K, int stride, int pad, int relu, void* stream) {
-    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1 || pad < 0 || stride < 1) return PMN_ERR_ARG;
+// in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][coutp/32][64][4] (params.pack_conv_mfma; coutp = cout rounded
+// up to 32, BatchNorm scale folded in); shift DEVICE float[coutp].
+//   planar == 0: out [N,Ho,Wo,cout] channels-last (out_b NULL, ca == cout == coutp, dil == 1); supported (cin,cout,K,stride):
+//                (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2)
+//   planar == 1: out [N,ca,Ho,Wo] and out_b [N,cout-ca,Ho,Wo] (NULL when ca == cout) planar; K = 3, stride 1, pad == dil;
+//                supported (cin,dil): (64,2), (32,4), (16,6) with cout <= 64 -- the offset heads of the default cascade
+extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const float* shift, float* out, float* out_b, int N,
+                               int H, int W, int cin, int cout, int ca, int K, int stride, int pad, int dil, int relu,
+                               int planar, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1 || pad < 0 || stride < 1 || dil < 1 || cout < 1)
+        return PMN_ERR_ARG;
+    if (ca < 1 || ca > cout || (ca < cout) != (out_b != nullptr)) return PMN_ERR_ARG;
     MfmaConvArgs a;
-    a.N = N; a.H = H; a.W = W; a.pad = pad; a.relu = relu;
-    a.Ho = (H + 2 * pad - K) / stride + 1;
-    a.Wo = (W + 2 * pad - K) / stride + 1;
+    a.N = N; a.H = H; a.W = W; a.pad = pad; a.relu = relu; a.cout = cout; a.ca = ca;
+    a.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+    a.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return PMN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (cin == 64 && cout == 64 && K == 3 && stride == 1) return launch_mfma<64, 32, 64, 3, 1, 2, 2, 4>(in, weights, shift, out, a, st);
-    if (cin == 32 && cout == 32 && K == 3 && stride == 1) return launch_mfma<32, 32, 32, 3, 1, 4, 2, 4>(in, weights, shift, out, a, st);
-    if (cin == 32 && cout == 64 && K == 5 && stride == 2) return launch_mfma<32, 8, 64, 5, 2, 2, 2, 5>(in, weights, shift, out, a, st);
-    if (cin == 16 && cout == 32 && K == 5 && stride == 2) return launch_mfma<16, 8, 32, 5, 2, 2, 2, 5>(in, weights, shift, out, a, st);
+    if (!planar) {
+        if (dil != 1 || ca != cout) return PMN_ERR_SHAPE;
+#define PMN_MFMA(CI, CCH, CO, KK, SS, NWV, PGV, DD) return launch_mfma<CI, CCH, CO, KK, SS, 1, NWV, PGV, DD, false>(in, weights, shift, out, out_b, a, st)
+        if (cin == 64 && cout == 64 && K == 3 && stride == 1) PMN_MFMA(64, 32, 64, 3, 1, 2, 2, 4);
+        if (cin == 32 && cout == 32 && K == 3 && stride == 1) PMN_MFMA(32, 32, 32, 3, 1, 4, 2, 4);
+        if (cin == 32 && cout == 64 && K == 5 && stride == 2) PMN_MFMA(32, 8, 64, 5, 2, 2, 2, 5);
+        if (cin == 16 && cout == 32 && K == 5 && stride == 2) PMN_MFMA(16, 8, 32, 5, 2, 2, 2, 5);
+#undef PMN_MFMA
+        return PMN_ERR_SHAPE;
+    }
+    if (K != 3 || stride != 1 || pad != dil || cout > 64) return PMN_ERR_SHAPE;
+#define PMN_HEAD(CI, CCH, DL, NWV, PGV, DD)                                                                              \
+    do {                                                                                                                 \
+        if (cout <= 32) return launch_mfma<CI, CCH, 32, 3, 1, DL, NWV, PGV, DD, true>(in, weights, shift, out, out_b, a, st); \
+        return launch_mfma<CI, CCH, 64, 3, 1, DL, NWV, PGV, DD, true>(in, weights, shift, out, out_b, a, st);             \
+    } while (0)
+    if (cin == 64 && dil == 2) PMN_HEAD(64, 32, 2, 2, 1, 4);  // 1/8 resolution: 4x16-pixel tiles, or the grid is < 1 wave per SIMD
+    if (cin == 32 && dil == 4) PMN_HEAD(32, 16, 4, 4, 1, 3);
+    if (cin == 16 && dil == 6) PMN_HEAD(16, 16, 6, 4, 2, 3);
+#undef PMN_HEAD
     return PMN_ERR_SHAPE;
 }

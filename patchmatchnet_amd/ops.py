@@ -350,12 +350,13 @@ def fpn_tail(x: torch.Tensor, up: torch.Tensor, w_in: torch.Tensor, b_in: torch.
 
 
 MFMA_CONV_SHAPES = {(64, 64, 3, 1), (32, 32, 3, 1), (32, 64, 5, 2), (16, 32, 5, 2)}  # (cin, cout, K, stride)
+MFMA_HEAD_SHAPES = {(64, 2), (32, 4), (16, 6)}  # (cin, dilation) of the planar offset-head form, cout <= 64
 
 
 def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: int, stride: int = 1, pad: int = 0,
                 relu: bool = True) -> torch.Tensor:
-    """pmn_conv2d_mfma: conv + folded-BN shift + ReLU as fp32 implicit GEMM on the matrix cores; x [N,H,W,cin] channels-last,
-    weights from params.pack_conv_mfma ([K*K, cin/8, cout/32, 64, 4]) -> [N,Ho,Wo,cout]."""
+    """pmn_conv2d_mfma (planar = 0): conv + folded-BN shift + ReLU as fp32 implicit GEMM on the matrix cores; x [N,H,W,cin]
+    channels-last, weights from params.pack_conv_mfma ([K*K, cin/8, cout/32, 64, 4]) -> [N,Ho,Wo,cout]."""
     for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
         _dev(t_, n_)
     N, H, W, cin = x.shape
@@ -365,9 +366,28 @@ def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: 
     Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
     out = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib().pmn_conv2d_mfma(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, H, W, cin,
-                                         cout, K, stride, pad, 1 if relu else 0, _stream(x)), "pmn_conv2d_mfma")
+        check(_lib.lib().pmn_conv2d_mfma(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), None, N, H, W,
+                                         cin, cout, cout, K, stride, pad, 1, 1 if relu else 0, 0, _stream(x)),
+              "pmn_conv2d_mfma")
     return out
+
+
+def offset_heads_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int, dil: int):
+    """pmn_conv2d_mfma (planar = 1): the offset heads of one stage (propa_conv rows first, then eval_conv; reference
+    models/patchmatch.py:288-311) as one dilated 3x3 convolution with bias; x [N,H,W,cin] channels-last, weights from
+    params.pack_conv_mfma of the row-concatenated filters -> ([N,ca,H,W], [N,cout-ca,H,W] or None) planar."""
+    for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    coutp = shift.shape[0]
+    if tuple(weights.shape) != (9, cin // 8, coutp // 32, 64, 4) or not 0 < ca <= cout <= coutp:
+        raise PmnError("offset_heads_mfma: weights are not in pack_conv_mfma layout for this input")
+    out_a = torch.empty((N, ca, H, W), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((N, cout - ca, H, W), dtype=torch.float32, device=x.device) if ca < cout else None
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d_mfma(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out_a.data_ptr(), _ptr(out_b), N,
+                                         H, W, cin, cout, ca, 3, 1, dil, dil, 0, 1, _stream(x)), "pmn_conv2d_mfma")
+    return out_a, out_b
 
 
 def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, ca: int):

@@ -122,13 +122,13 @@ def fold_fpn(output1, inner1, b_inner1, inner2, b_inner2, output2, output3):
 
 
 def pack_conv_mfma(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
-    """Conv2d weight [cout,cin,K,K] (+ BatchNorm2d tensors or a conv bias) -> (float32 [K*K, cin/8, cout/32, 64, 4],
-    float32 [cout]) in the B-operand order of pmn_conv2d_mfma: lane (h = lane>>5, i = lane&31) of column block nt reads the four
+    """Conv2d weight [cout,cin,K,K] (+ BatchNorm2d tensors or a conv bias) -> (float32 [K*K, cin/8, coutp/32, 64, 4],
+    float32 [coutp]), coutp = cout rounded up to 32, in the B-operand order of pmn_conv2d_mfma: lane (h = lane>>5, i = lane&31) of column block nt reads the four
     weights w[nt*32 + i][8*c8 + 4*h + j][ky][kx], j = 0..3, as one 16-byte load.  BatchNorm folded in float64."""
     w = _np64(weight)
     cout, cin, K, _ = w.shape
-    if cin % 8 or cout % 32:
-        raise ValueError("pack_conv_mfma: cin must be a multiple of 8 and cout a multiple of 32")
+    if cin % 8:
+        raise ValueError("pack_conv_mfma: cin must be a multiple of 8")
     if bn is not None:
         g, b, m, v = (_np64(t) for t in bn)
         s = g / np.sqrt(v + eps)
@@ -138,6 +138,10 @@ def pack_conv_mfma(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS
         shift = _np64(bias)
     else:
         shift = np.zeros(cout)
+    coutp = (cout + 31) // 32 * 32  # zero rows pad the last column block
+    w = np.concatenate([w, np.zeros((coutp - cout, cin, K, K))], 0)
+    shift = np.concatenate([shift, np.zeros(coutp - cout)])
+    cout = coutp
     # [cout, cin, ky, kx] -> [ky, kx, c8, h, j, nt, i] -> [tap, c8, nt, h, i, j]
     t = w.transpose(2, 3, 1, 0).reshape(K * K, cin // 8, 2, 4, cout // 32, 32)
     t = t.transpose(0, 1, 4, 2, 5, 3).reshape(K * K, cin // 8, cout // 32, 64, 4)

@@ -190,6 +190,7 @@ class PatchMatch(nn.Module):
 
         # offset heads through pmn_conv2d (True) or MIOpen (False)
         self.hip_offset_heads = True
+        self.mfma_offset_heads = True  # ... and on the matrix cores (pmn_conv2d_mfma, both heads in one launch) when supported
         self._heads = None
         self._heads_key = None
         self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
@@ -204,6 +205,14 @@ class PatchMatch(nn.Module):
             for name, m in (("propa", self.propa_conv), ("eval", self.eval_conv)):
                 w, s = params.pack_conv(m.weight, bias=m.bias)
                 pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            # matrix-core form: both heads as ONE convolution (propa rows, then eval rows), with and without the propa rows
+            if (self.eval_conv.in_channels, self.dilation) in ops.MFMA_HEAD_SHAPES:
+                for name, mods in (("both", (self.propa_conv, self.eval_conv)), ("eval_only", (self.eval_conv,))):
+                    wcat = torch.cat([m.weight.detach() for m in mods], 0)
+                    bcat = torch.cat([m.bias.detach() for m in mods], 0)
+                    if wcat.shape[0] <= 64:
+                        w, s = params.pack_conv_mfma(wcat, bias=bcat)
+                        pk["mfma_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             self._heads, self._heads_key = pk, key
         return self._heads
 
@@ -233,10 +242,16 @@ class PatchMatch(nn.Module):
         if self.hip_offset_heads:
             # offset heads as HIP convolutions on the channels-last reference feature, planar [B,2K,h,w] output
             pk = self._packed_heads()
-            propa_offsets = ops.conv2d(ref_nhwc, *pk["propa"], 2 * self.propagate_neighbors, 3, 1, self.dilation,
-                                       self.dilation, out_nchw=True) if propagate_any else None
-            eval_offsets = ops.conv2d(ref_nhwc, *pk["eval"], 2 * self.evaluate_neighbors, 3, 1, self.dilation,
-                                      self.dilation, out_nchw=True)
+            key = "mfma_both" if propagate_any else "mfma_eval_only"
+            if self.mfma_offset_heads and key in pk:
+                n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
+                a_, b_ = ops.offset_heads_mfma(ref_nhwc, *pk[key], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
+                propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)
+            else:
+                propa_offsets = ops.conv2d(ref_nhwc, *pk["propa"], 2 * self.propagate_neighbors, 3, 1, self.dilation,
+                                           self.dilation, out_nchw=True) if propagate_any else None
+                eval_offsets = ops.conv2d(ref_nhwc, *pk["eval"], 2 * self.evaluate_neighbors, 3, 1, self.dilation,
+                                          self.dilation, out_nchw=True)
         else:
             ref_feature = ref_feature.contiguous()
             propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None

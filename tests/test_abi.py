@@ -179,3 +179,8 @@ def test_pack_conv_mfma_layout():
     p2, s2 = PR.pack_conv_mfma(w, bn=bn)
     np.testing.assert_allclose(p2, p, rtol=1e-6)          # scale = 2 / sqrt(4) = 1
     np.testing.assert_allclose(s2, 0.5 - 0.25, rtol=1e-6)
+    # output channels are padded to a multiple of 32 with zero filters (the fused offset heads have 18..50 channels)
+    p3, s3 = PR.pack_conv_mfma(w[:50], bias=torch.arange(50, dtype=torch.float32))
+    assert p3.shape == (25, 4, 2, 64, 4) and s3.shape == (64,)
+    np.testing.assert_array_equal(p3[:, :, 0], p[:, :, 0])
+    assert not p3[:, :, 1, 18:32].any() and not p3[:, :, 1, 32 + 18:].any() and not s3[50:].any() and s3[49] == 49

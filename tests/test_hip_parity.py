@@ -284,6 +284,30 @@ def test_conv2d_mfma_against_torch(cin, cout, K, stride, H, W):
     assert float((got - valu).abs().max() / ref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,dil,n_p,n_e", [(64, 2, 32, 18), (64, 2, 0, 18), (32, 4, 16, 18), (32, 4, 16, 34), (16, 6, 0, 18),
+                                             (16, 6, 8, 18)])
+@pytest.mark.parametrize("H,W,N", [(37, 50, 2), (16, 16, 1)])
+def test_offset_heads_mfma_against_torch(cin, dil, n_p, n_e, H, W, N):
+    """pmn_conv2d_mfma planar form: propa_conv + eval_conv of a stage as one dilated 3x3 convolution on the matrix cores vs
+    F.conv2d (float64) per head, ragged tiles, batch > 1, padded channel blocks."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin + dil + n_p + H)
+    x = torch.randn(N, cin, H, W, generator=gen)
+    heads = [(0.1 * torch.randn(c, cin, 3, 3, generator=gen), 0.1 * torch.randn(c, generator=gen)) for c in (n_p, n_e) if c]
+    wcat, bcat = torch.cat([w for w, _ in heads], 0), torch.cat([b for _, b in heads], 0)
+    w, sh = PP.pack_conv_mfma(wcat, bias=bcat)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ca = n_p if n_p else n_e
+    a, b = P.ops.offset_heads_mfma(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), n_p + n_e, ca, dil)
+    outs = [a] if b is None else [a, b]
+    assert len(outs) == len(heads)
+    for got, (wt, bias) in zip(outs, heads):
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), 1, dil, dil)
+        assert tuple(got.shape) == tuple(ref.shape) and got.is_contiguous()
+        assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_featurenet_hip_matches_miopen(fold):
     """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels, with the FPN
