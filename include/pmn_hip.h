@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 6
+#define PMN_ABI_VERSION 7
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -156,6 +156,18 @@ int pmn_fpn_level(const float *x, const float *u, const float *w, const float *b
  * folded in: patchmatchnet_amd/params.py pack_deconv); shift DEVICE float[8] -> out [N,2Hi,2Wi,8]. */
 int pmn_deconv3x3s2(const float *in, const float *weights, const float *shift, float *out, int N, int Hi, int Wi, int cin,
                     int cout, int relu, void *stream);
+
+/* Full-resolution half of the Refinement network (reference models/net.py:73-126) in two launches.
+ * pmn_refine_front: x16 = cat( relu(bn(deconv(t2))), conv0(img) ) (net.py:110-117): img [B,3,H,W] planar, t2 [B,H/2,W/2,8]
+ *   channels-last (conv2 output); w0 [3][3][3][8] / s0 [8] = pack_conv of conv0, wd [3][3][8][8] / sd [8] = pack_deconv of
+ *   deconv + bn (DEVICE) -> x16 [B,H,W,16].  H, W even.
+ * pmn_refine_tail: depth = (nearest_x2(dnorm) + res(conv3(x16))) * (depth_max - depth_min) + depth_min (net.py:117-122):
+ *   w3 [2][3][3][16][4] / s3 [8] and wr [3][3][8] from patchmatchnet_amd/params.py pack_refine_tail (DEVICE); dnorm
+ *   [B,1,H/2,W/2] normalised input depth; depth_min / depth_max DEVICE float[B] -> out [B,1,H,W]. */
+int pmn_refine_front(const float *img, const float *t2, const float *w0, const float *s0, const float *wd, const float *sd,
+                     float *x16, int B, int H, int W, void *stream);
+int pmn_refine_tail(const float *x16, const float *w3, const float *s3, const float *wr, const float *dnorm,
+                    const float *depth_min, const float *depth_max, float *out, int B, int H, int W, void *stream);
 
 /* Relative projections of every (stage, batch element, source view): rel = P_src @ inverse(P_ref) with
  * P = [[K_s @ E[:3,:4]], [E[3,:]]] and K_s = K with rows 0,1 scaled by scale0 * 2^stage (reference models/net.py:225-231,

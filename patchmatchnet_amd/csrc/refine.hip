@@ -1,0 +1,238 @@
+// refine.hip -- the full-resolution part of the Refinement network (reference models/net.py:73-126) in two kernels.
+//
+// Layer by layer (conv0 on the image, the transposed convolution, torch.cat, conv3, res, and four element-wise passes) the
+// full-resolution half of Refinement moves ~0.9 GB per 1600x1200 depth map through HBM in ten launches for 1.6 GFLOP of work.
+//   pmn_refine_front   x16 = cat( relu(bn(deconv(t))), conv0(img) )         image + half-resolution features -> [B,H,W,16]
+//   pmn_refine_tail    depth = (nearest_x2(d) + res(conv3(x16))) * span + min                    [B,H,W,16] -> [B,1,H,W]
+// Both own a 16x16 tile of output pixels per 256-thread workgroup, stage what they read in LDS with every load of a thread
+// in flight at once, and feed the FMAs wave-uniform SGPR weights ([ky][kx][ci][co] layouts of params.pack_conv / pack_deconv).
+#include "pmn_common.hpp"
+
+typedef const float __attribute__((address_space(4))) cfloat;
+
+// ---- front: conv0 (3 -> 8, BN, ReLU; net.py:82,110) || ConvTranspose2d(8,8,3,s2,p1,op1) + BN + ReLU (net.py:86-88,114) -----------
+// out[oy,ox] of the transposed convolution = sum over (ky,kx) with (oy+1-ky), (ox+1-kx) even of in[(oy+1-ky)/2,(ox+1-kx)/2] w[ky][kx]:
+// even coordinates take tap 1 of in[y], odd ones tap 2 of in[y] and tap 0 of in[y+1].  Wave w of the workgroup owns parity class
+// (py,px) = (w>>1, w&1) of the tile -- 8x8 pixels at stride 2 -- so the tap set is wave-uniform (scalar branches, SGPR weights).
+__global__ __launch_bounds__(PMN_BLOCK) void refine_front_kernel(const float* __restrict__ img, const float* __restrict__ t2,
+                                                                 const float* __restrict__ w0, const float* __restrict__ s0,
+                                                                 const float* __restrict__ wd, const float* __restrict__ sd,
+                                                                 float* __restrict__ x16, int B, int H, int W) {
+    constexpr int TW = 16, TH = 16, IW = 18, IWP = 19, TP = 9, TPP = 12;  // image patch 18x18 (pitch 19), t2 patch 9x9 px x 12 words
+    __shared__ float xin[3 * IW * IWP];
+    __shared__ float4 tp4[TP * TP * TPP / 4];
+    float* tp = reinterpret_cast<float*>(tp4);
+    const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
+    const cfloat* cs0 = (const cfloat*)s0;
+    const cfloat* cwd = (const cfloat*)wd;  // [3][3][8][8]
+    const cfloat* csd = (const cfloat*)sd;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, B * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int Hi = H / 2, Wi = W / 2, iy0 = oy0 / 2, ix0 = ox0 / 2;
+
+    {
+        constexpr int NL = (3 * IW * IW + PMN_BLOCK - 1) / PMN_BLOCK;  // 4
+        float v[NL];
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * PMN_BLOCK;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
+            v[k] = 0.0f;
+            if (idx < 3 * IW * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v[k] = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
+        }
+        const int upix = tid >> 1, uq = tid & 1;  // 81 pixels x 2 float4
+        if (upix < TP * TP) {
+            const int gy = iy0 + upix / TP, gx = ix0 + upix % TP;
+            if (gy < Hi && gx < Wi) u = *reinterpret_cast<const float4*>(t2 + (((size_t)n * Hi + gy) * Wi + gx) * 8 + 4 * uq);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * PMN_BLOCK;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            if (idx < 3 * IW * IW) xin[(c * IW + r) * IWP + q] = v[k];
+        }
+        if (upix < TP * TP) *reinterpret_cast<float4*>(tp + upix * TPP + 4 * uq) = u;
+    }
+    __syncthreads();
+
+    const int py = wave >> 1, px = wave & 1, yy = lane >> 3, xx = lane & 7;
+    const int ty = 2 * yy + py, tx = 2 * xx + px;  // pixel inside the tile
+    float up[8], f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { up[c] = 0.0f; f[c] = 0.0f; }
+
+    // transposed convolution: taps valid for this wave's parity class
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        if ((py == 0) != (ky == 1)) continue;  // even rows: ky = 1; odd rows: ky = 0 (input row y+1) and ky = 2 (row y)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if ((px == 0) != (kx == 1)) continue;
+            const float* ip = tp + ((yy + (ky == 0 ? 1 : 0)) * TP + xx + (kx == 0 ? 1 : 0)) * TPP;
+            const float4 a = *reinterpret_cast<const float4*>(ip), b = *reinterpret_cast<const float4*>(ip + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const cfloat* wq = cwd + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * 64);
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) up[c] = fmaf(v[ci], wq[ci * 8 + c], up[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // conv0 on the image
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = xin[(ci * IW + ty + ky) * IWP + tx + kx];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) f[c] = fmaf(v, cw0[((ky * 3 + kx) * 3 + ci) * 8 + c], f[c]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= H || ox >= W) return;
+    float* op = x16 + (((size_t)n * H + oy) * W + ox) * 16;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        up[c] = fmaxf(up[c] + csd[c], 0.0f);
+        f[c] = fmaxf(f[c] + cs0[c], 0.0f);
+    }
+    *reinterpret_cast<float4*>(op) = make_float4(up[0], up[1], up[2], up[3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(up[4], up[5], up[6], up[7]);
+    *reinterpret_cast<float4*>(op + 8) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(op + 12) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// img [B,3,H,W] planar; t2 [B,H/2,W/2,8] (conv2 output, channels-last); w0 [3][3][3][8] / s0 [8] (pack_conv of conv0);
+// wd [3][3][8][8] / sd [8] (pack_deconv of deconv + bn) -> x16 [B,H,W,16] = (deconv branch | image branch) as net.py:117 concatenates
+extern "C" int pmn_refine_front(const float* img, const float* t2, const float* w0, const float* s0, const float* wd,
+                                const float* sd, float* x16, int B, int H, int W, void* stream) {
+    if (!img || !t2 || !w0 || !s0 || !wd || !sd || !x16 || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMN_ERR_ARG;
+    const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(refine_front_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, t2, w0, s0, wd, sd, x16, B,
+                       H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// ---- tail: conv3 (16 -> 8, BN, ReLU; net.py:90,117) -> res (8 -> 1, no bias; net.py:92,117) -> residual + de-normalisation ---------
+// conv3 is evaluated on the 18x18 halo patch into LDS (positions outside the image are ZERO: res pads conv3's output map) in
+// 12 wave-passes of (one half of the 8 output channels) x (64 pixels) -- the half is wave-uniform, so the weights stay in
+// SGPRs; then every thread forms its pixel's residual from ds_read_b128's.
+__global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __restrict__ x16, const float* __restrict__ w3,
+                                                                const float* __restrict__ s3, const float* __restrict__ wr,
+                                                                const float* __restrict__ dnorm,
+                                                                const float* __restrict__ dmin, const float* __restrict__ dmax,
+                                                                float* __restrict__ out, int B, int H, int W) {
+    constexpr int TW = 16, TH = 16, IW = 20, XP = 20, MW = 18, MP = 12;  // x16 patch 20x20 px x 20 words, conv3 map 18x18 px x 12 words
+    extern __shared__ float4 rt_lds4[];
+    float* xs = reinterpret_cast<float*>(rt_lds4);
+    float* mid = xs + IW * IW * XP;
+    const cfloat* cw3 = (const cfloat*)w3;  // [2 halves][3][3][16][4]
+    const cfloat* cs3 = (const cfloat*)s3;
+    const cfloat* cwr = (const cfloat*)wr;  // [3][3][8]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, tx = tid % TW, ty = tid / TW;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, B * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+
+    {
+        constexpr int TOT = IW * IW * 4, NL = (TOT + PMN_BLOCK - 1) / PMN_BLOCK;  // 1600 float4, 7 per thread
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * PMN_BLOCK, pix = idx >> 2, q = idx & 3;
+            const int gy = oy0 - 2 + pix / IW, gx = ox0 - 2 + pix % IW;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v[k] = *reinterpret_cast<const float4*>(x16 + (((size_t)n * H + gy) * W + gx) * 16 + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * PMN_BLOCK, pix = idx >> 2, q = idx & 3;
+            if (idx < TOT) *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) = v[k];
+        }
+    }
+    __syncthreads();
+
+    // conv3: 2 halves (4 output channels each) x 6 groups of 64 pixels = 12 wave-passes over 4 waves
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        const int wp = p * 4 + wave, half = wp / 6, m = (wp % 6) * 64 + lane;
+        const int mc = min(m, MW * MW - 1), r = mc / MW, q = mc - r * MW;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const cfloat* wh = cw3 + __builtin_amdgcn_readfirstlane(half * 576);
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll 1
+            for (int kx = 0; kx < 3; ++kx) {  // rolled: one tap's 64 weights in SGPRs at a time (unrolled, hipcc hoists all 576 and spills)
+                const float* ip = xs + ((r + ky) * IW + q + kx) * XP;
+                const cfloat* wq = wh + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * 64);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float4 a = *reinterpret_cast<const float4*>(ip + 4 * c4);
+                    const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[k], wq[(4 * c4 + k) * 4 + c], acc[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
+        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const cfloat* sh = cs3 + __builtin_amdgcn_readfirstlane(half * 4);
+        float4 o;
+        o.x = inside ? fmaxf(acc[0] + sh[0], 0.0f) : 0.0f;
+        o.y = inside ? fmaxf(acc[1] + sh[1], 0.0f) : 0.0f;
+        o.z = inside ? fmaxf(acc[2] + sh[2], 0.0f) : 0.0f;
+        o.w = inside ? fmaxf(acc[3] + sh[3], 0.0f) : 0.0f;
+        if (m < MW * MW) *reinterpret_cast<float4*>(mid + m * MP + half * 4) = o;
+    }
+    __syncthreads();
+
+    float res = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* mp = mid + ((ty + ky) * MW + tx + kx) * MP;
+            const float4 a = *reinterpret_cast<const float4*>(mp), b = *reinterpret_cast<const float4*>(mp + 4);
+            const cfloat* wq = cwr + (ky * 3 + kx) * 8;
+            res = fmaf(a.x, wq[0], res); res = fmaf(a.y, wq[1], res); res = fmaf(a.z, wq[2], res); res = fmaf(a.w, wq[3], res);
+            res = fmaf(b.x, wq[4], res); res = fmaf(b.y, wq[5], res); res = fmaf(b.z, wq[6], res); res = fmaf(b.w, wq[7], res);
+        }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= H || ox >= W) return;
+    {
+#pragma clang fp contract(off)
+        const float lo = dmin[n], span = dmax[n] - lo;
+        const float d = dnorm[((size_t)n * (H / 2) + (oy >> 1)) * (W / 2) + (ox >> 1)] + res;  // nearest x2 + residual (net.py:119)
+        out[((size_t)n * H + oy) * W + ox] = d * span + lo;                                     // net.py:122
+    }
+}
+
+// x16 [B,H,W,16] (pmn_refine_front); w3 [2][3][3][16][4] (conv3, BN folded, output channels split in two halves of 4:
+// params.pack_refine_tail) / s3 [8]; wr [3][3][8] (res weight, [ky][kx][ci]);
+// dnorm [B,1,H/2,W/2] = (depth - depth_min) / (depth_max - depth_min); depth_min / depth_max DEVICE float[B] -> out [B,1,H,W]
+extern "C" int pmn_refine_tail(const float* x16, const float* w3, const float* s3, const float* wr, const float* dnorm,
+                               const float* depth_min, const float* depth_max, float* out, int B, int H, int W, void* stream) {
+    if (!x16 || !w3 || !s3 || !wr || !dnorm || !depth_min || !depth_max || !out || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return PMN_ERR_ARG;
+    const size_t lds = (size_t)(20 * 20 * 20 + 18 * 18 * 12) * sizeof(float);  // 47.6 KB
+    const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(refine_tail_kernel, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, x16, w3, s3, wr, dnorm,
+                       depth_min, depth_max, out, B, H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

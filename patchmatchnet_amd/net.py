@@ -130,6 +130,7 @@ class Refinement(nn.Module):
         self.bn = nn.BatchNorm2d(8)
         self.conv3 = ConvBnReLU(in_channels=16, out_channels=8)
         self.res = nn.Conv2d(8, 1, kernel_size=3, padding=1, bias=False)
+        self.fused_tail = True  # forward_hip: pmn_refine_front + pmn_refine_tail (False = one launch per layer)
 
     def _packed(self):
         srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
@@ -149,6 +150,8 @@ class Refinement(nn.Module):
             pk["deconv"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             w, s = params.pack_conv(self.res.weight)
             pk["res"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            pk["tail"] = tuple(torch.from_numpy(a).to(dev) for a in params.pack_refine_tail(
+                self.conv3.conv.weight, bn_of(self.conv3.bn), self.res.weight, eps=self.conv3.bn.eps))
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -160,9 +163,13 @@ class Refinement(nn.Module):
         lo = depth_min.view(b, 1, 1, 1)
         span = (depth_max - depth_min).view(b, 1, 1, 1)
         d = ((depth_0 - lo) / span).contiguous()
-        img_feat = ops.conv2d(img.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True)      # [B,H,W,8]
         t = ops.conv2d(d, *pk["conv1"], 8, 3, 1, 1, relu=True, in_nchw=True)                             # [B,H/2,W/2,8]
         t = ops.conv2d(t, *pk["conv2"], 8, 3, 1, 1, relu=True)
+        if self.fused_tail and img.shape[2] % 2 == 0 and img.shape[3] % 2 == 0:
+            # full-resolution half in two launches: (deconv || conv0) -> x16, then conv3 -> res -> residual + de-normalisation
+            x16 = ops.refine_front(img.contiguous(), t, *pk["conv0"], *pk["deconv"])
+            return ops.refine_tail(x16, *pk["tail"], d, depth_min.float().contiguous(), depth_max.float().contiguous())
+        img_feat = ops.conv2d(img.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True)      # [B,H,W,8]
         up = ops.deconv3x3s2(t, *pk["deconv"], relu=True)                                                # [B,H,W,8]
         t = ops.conv2d(torch.cat((up, img_feat), dim=3), *pk["conv3"], 8, 3, 1, 1, relu=True)
         res = ops.conv2d(t, *pk["res"], 1, 3, 1, 1, out_nchw=True)                                       # [B,1,H,W]

@@ -412,6 +412,42 @@ def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: to
     return out_a, out_b
 
 
+def refine_front(img: torch.Tensor, t2: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, wd: torch.Tensor,
+                 sd: torch.Tensor) -> torch.Tensor:
+    """pmn_refine_front: cat(relu(bn(deconv(t2))), conv0(img)) of Refinement (reference models/net.py:110-117); img [B,3,H,W],
+    t2 [B,H/2,W/2,8] channels-last -> [B,H,W,16]."""
+    for n_, t_ in (("img", img), ("t2", t2), ("w0", w0), ("s0", s0), ("wd", wd), ("sd", sd)):
+        _dev(t_, n_)
+    B, c, H, W = img.shape
+    if c != 3 or H % 2 or W % 2 or tuple(t2.shape) != (B, H // 2, W // 2, 8) or tuple(w0.shape) != (3, 3, 3, 8) or \
+            tuple(wd.shape) != (3, 3, 8, 8):
+        raise PmnError("refine_front: inconsistent shapes")
+    out = torch.empty((B, H, W, 16), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        check(_lib.lib().pmn_refine_front(img.data_ptr(), t2.data_ptr(), w0.data_ptr(), s0.data_ptr(), wd.data_ptr(),
+                                          sd.data_ptr(), out.data_ptr(), B, H, W, _stream(img)), "pmn_refine_front")
+    return out
+
+
+def refine_tail(x16: torch.Tensor, w3: torch.Tensor, s3: torch.Tensor, wr: torch.Tensor, dnorm: torch.Tensor,
+                depth_min: torch.Tensor, depth_max: torch.Tensor) -> torch.Tensor:
+    """pmn_refine_tail: (nearest_x2(dnorm) + res(conv3(x16))) * (depth_max - depth_min) + depth_min (reference
+    models/net.py:117-122); x16 [B,H,W,16], dnorm [B,1,H/2,W/2], depth_min / depth_max [B] -> [B,1,H,W]."""
+    for n_, t_ in (("x16", x16), ("w3", w3), ("s3", s3), ("wr", wr), ("dnorm", dnorm), ("depth_min", depth_min),
+                   ("depth_max", depth_max)):
+        _dev(t_, n_)
+    B, H, W, c = x16.shape
+    if c != 16 or H % 2 or W % 2 or tuple(dnorm.shape) != (B, 1, H // 2, W // 2) or tuple(w3.shape) != (2, 3, 3, 16, 4) or \
+            tuple(wr.shape) != (3, 3, 8) or depth_min.numel() != B or depth_max.numel() != B:
+        raise PmnError("refine_tail: inconsistent shapes")
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x16.device)
+    with torch.cuda.device(x16.device):
+        check(_lib.lib().pmn_refine_tail(x16.data_ptr(), w3.data_ptr(), s3.data_ptr(), wr.data_ptr(), dnorm.data_ptr(),
+                                         depth_min.data_ptr(), depth_max.data_ptr(), out.data_ptr(), B, H, W, _stream(x16)),
+              "pmn_refine_tail")
+    return out
+
+
 def deconv3x3s2(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """pmn_deconv3x3s2: ConvTranspose2d(k3,s2,p1,op1) + folded BN + ReLU; x [N,Hi,Wi,8] -> [N,2Hi,2Wi,8]."""
     _dev(x, "x")

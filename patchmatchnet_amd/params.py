@@ -148,6 +148,16 @@ def pack_conv_mfma(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS
     return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
 
 
+def pack_refine_tail(conv3_weight, conv3_bn, res_weight, eps: float = BN_EPS):
+    """Refinement.conv3 (Conv2d 16->8 + BatchNorm) and Refinement.res (Conv2d 8->1, no bias) -> (w3 float32 [2,3,3,16,4],
+    s3 float32 [8], wr float32 [3,3,8]) for pmn_refine_tail: conv3's output channels split into two halves of four (a half is
+    wave-uniform in the kernel), BatchNorm folded in float64."""
+    w, s = pack_conv(conv3_weight, bn=conv3_bn, eps=eps)  # [3,3,16,8], [8]
+    w3 = np.ascontiguousarray(w.reshape(3, 3, 16, 2, 4).transpose(3, 0, 1, 2, 4))
+    wr = np.ascontiguousarray(_np64(res_weight)[0].transpose(1, 2, 0).astype(np.float32))  # [1,8,3,3] -> [3,3,8]
+    return w3, s, wr
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

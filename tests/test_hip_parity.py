@@ -349,17 +349,22 @@ def test_stage_projections_kernel():
                 assert np.abs(rel[s, b, v - 1] - want).max() / np.abs(want).max() < 2e-6
 
 
-def test_refinement_hip_matches_miopen():
-    """Refinement through pmn_conv2d / pmn_deconv3x3s2 vs the same module on PyTorch-ROCm (MIOpen)."""
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,H,W", [(1, 96, 128), (2, 50, 70)])
+def test_refinement_hip_matches_miopen(fused, B, H, W):
+    """Refinement through pmn_refine_front / pmn_refine_tail (fused) or pmn_conv2d / pmn_deconv3x3s2 (layer by layer) vs the
+    same module on PyTorch-ROCm (MIOpen); ragged tiles and batch > 1 included."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
-    img = t(g["image_0"])
-    gen = torch.Generator().manual_seed(5)
-    d0 = (425.0 + 510.0 * torch.rand(1, 1, img.shape[2] // 2, img.shape[3] // 2, generator=gen)).to(DEV)
+    model.upsample_net.fused_tail = fused
+    gen = torch.Generator().manual_seed(5 + H)
+    img = torch.rand(B, 3, H, W, generator=gen).to(DEV)
+    d0 = (425.0 + 510.0 * torch.rand(B, 1, H // 2, W // 2, generator=gen)).to(DEV)
+    dmin, dmax = t(np.full(B, 425.0, np.float32)), t(np.linspace(935.0, 1000.0, B).astype(np.float32))
     with torch.no_grad():
-        ref = model.upsample_net(img, d0, t(g["depth_min"]), t(g["depth_max"]))
-        got = model.upsample_net.forward_hip(img, d0, t(g["depth_min"]), t(g["depth_max"]))
+        ref = model.upsample_net(img, d0, dmin, dmax)
+        got = model.upsample_net.forward_hip(img, d0, dmin, dmax)
     assert got.shape == ref.shape
     assert float(((got - ref).abs() / ref.abs()).max()) < 1e-5
 
