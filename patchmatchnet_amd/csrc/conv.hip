@@ -371,16 +371,20 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        // tap rows ROLLED here and below: fully unrolled, hipcc's SLP pass gives up on the block and emits 792 scalar v_fma_f32
+        // (half the packed-FMA rate) for the kernel
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const cfloat* wq = cw0 + __builtin_amdgcn_readfirstlane(ky * 72);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
                     const float v = xin[(ci * IW + r + ky) * IWP + q + kx];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, cw0[((ky * 3 + kx) * 3 + ci) * 8 + c], acc[c]);
+                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wq[(kx * 3 + ci) * 8 + c], acc[c]);
                 }
+        }
         const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = inside ? fmaxf(acc[c] + cs0[c], 0.0f) : 0.0f;
@@ -391,18 +395,18 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
     float o[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) o[c] = 0.0f;
-#pragma unroll
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
+#pragma unroll 1
         for (int kx = 0; kx < 3; ++kx) {
             const float* mp = mid + ((ty + ky) * MW + tx + kx) * MP;
             const float4 a = *reinterpret_cast<const float4*>(mp), b = *reinterpret_cast<const float4*>(mp + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const cfloat* wq = cw1 + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * 64);
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = fmaf(v[ci], cw1[((ky * 3 + kx) * 8 + ci) * 8 + c], o[c]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < 8; ++c) o[c] = fmaf(v[ci], wq[ci * 8 + c], o[c]);
         }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= H || ox >= W) return;

@@ -86,17 +86,17 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_front_kernel(const float* __
         }
     }
     // conv0 on the image
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {  // rolled: fully unrolled, hipcc emits scalar v_fma_f32 instead of packed FMAs for this block
+        const cfloat* wq = cw0 + __builtin_amdgcn_readfirstlane(ky * 72);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
                 const float v = xin[(ci * IW + ty + ky) * IWP + tx + kx];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) f[c] = fmaf(v, cw0[((ky * 3 + kx) * 3 + ci) * 8 + c], f[c]);
+                for (int c = 0; c < 8; ++c) f[c] = fmaf(v, wq[(kx * 3 + ci) * 8 + c], f[c]);
             }
-        __builtin_amdgcn_sched_barrier(0);
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= H || ox >= W) return;
