@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 7
+#define PMN_ABI_VERSION 8
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -70,7 +70,8 @@ int pmn_feature_weight(const float *ref_nhwc, const float *eval_offsets, const i
  *   K > 0         : the centre hypothesis (index D0/2) is gathered at the K propagation neighbours, appended, and
  *                   the D = D0 + K values are sorted ascending per pixel.
  * depth_min/depth_max: device float[B].  Outputs: depth_sample [B,D,h,w] and its normalised inverse depth
- * xnorm [B,D,h,w] = (1/d - 1/dmax)/(1/dmin - 1/dmax) (reference :655-657), used by pmn_aggregate_regress. */
+ * xnorm = (1/d - 1/dmax)/(1/dmin - 1/dmax) (reference :655-657), stored HYPOTHESIS-LAST [B,h,w,D] for
+ * pmn_aggregate_regress (its only consumer: one bilinear corner of a neighbour = D contiguous floats). */
 int pmn_init_hypotheses(const float *noise, const float *depth, int depth_shift, const float *depth_min,
                         const float *depth_max, int num_sample, float interval_scale, const float *propa_offsets,
                         const int *propa_table_host, int K, int B, int h, int w, float *depth_sample,
@@ -83,7 +84,8 @@ int pmn_init_hypotheses(const float *noise, const float *depth, int depth_shift,
  * view weights either read from view_weights_in ([B,N,h>>vw_shift,w>>vw_shift]; vw_shift = 1 / 2 reads a
  * coarser stage's map through the nearest x2 / x4 up-sampling of net.py:275) or -- view_weights_in == NULL -- computed by PixelwiseNet (max over D of the
  * sigmoid response) and written to view_weights_out [B,N,h,w] (+ optional arg-max index vw_argmax_out);
- * weighted aggregation over views; SimilarityNet MLP -> cost_out [B,D,h,w].
+ * weighted aggregation over views; SimilarityNet MLP -> cost_out, stored HYPOTHESIS-LAST [B,h,w,D] (consumed only by
+ * pmn_aggregate_regress).
  * rel_proj [B,N,4,4] = src_proj @ inverse(ref_proj).  similarity_out (optional) receives the aggregated
  * similarity [B,G,D,h,w] (the tensor the reference materialises at :217).
  * The warped volume [B,C,D,h,w] is never materialised. */
@@ -96,7 +98,8 @@ int pmn_warp_correlate(const float *ref_nhwc, const float *src_nhwc, const float
 /* Adaptive spatial cost aggregation + softmax + regression: depth_weight (reference models/patchmatch.py:650-669),
  * weight normalisation (:509-510), SimilarityNet's neighbour gather and weighted sum (:569-577),
  * exp(log_softmax) (:221) and depth regression (:226-237).
- * score_out [B,D,h,w] = probabilities, depth_out [B,h,w].  is_inverse selects the inverse-depth regression. */
+ * cost and xnorm are hypothesis-last [B,h,w,D] (as pmn_warp_correlate / pmn_init_hypotheses write them); depth_sample
+ * [B,D,h,w]; score_out [B,D,h,w] = probabilities, depth_out [B,h,w].  is_inverse selects the inverse-depth regression. */
 int pmn_aggregate_regress(const float *cost, const float *depth_sample, const float *xnorm,
                           const float *feature_weight, const float *eval_offsets, const int *eval_table_host,
                           int K, float interval_scale, int is_inverse, int B, int D, int h, int w,

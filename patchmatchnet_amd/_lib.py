@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17

@@ -2,20 +2,25 @@
 // Reference: models/patchmatch.py:650-669 (depth_weight), :509-510 (weight normalisation), :569-577 (SimilarityNet
 // neighbour gather + weighted sum), :221 (exp(log_softmax)), :226-237 (regression).
 //
-// A thread owns a pixel and a strided subset of its hypotheses.  The K neighbour tap sets (offset + 4 corner weights) and
-// the K feature weights are computed once and kept in registers; for every hypothesis d the thread gathers the neighbour's normalised inverse depth and
-// pointwise cost at the same taps (both planes are [D,h,w], x fastest, so a wave's taps of one corner are a nearly
-// contiguous run), forms the depth weight, normalises over the K neighbours and accumulates the aggregated score.
-// The D scores are parked in the output score buffer (each thread re-reads only its own column) for the softmax and
-// the regression; the [B,D,K,h,w] weight tensor of the reference is never materialised.
+// The pointwise cost and the normalised inverse depth arrive HYPOTHESIS-LAST ([B,h,w,D]): the K neighbour tap sets of a pixel
+// do not depend on d, so one bilinear corner is D contiguous floats and a thread fetches four hypotheses per 16-byte load
+// (planar [B,D,h,w] maps cost one 4-byte gather per corner per hypothesis: 72 address-limited gathers per (pixel, d), which
+// bound the planar version of this kernel at 70-170 us per launch).
+//
+// Main kernel (D % 4 == 0): a thread owns (pixel, quad of 4 consecutive hypotheses); the D/4 threads of a pixel are adjacent
+// lanes, so their corner loads are one contiguous run.  The K tap sets (offset + 4 corner weights) and feature weights are
+// formed once per thread and kept in registers; per neighbour the thread forms 4 depth weights and 4 sampled costs, then
+// normalises over the K neighbours exactly in the reference's order.  Softmax and regression partials are combined across
+// the pixel's threads through LDS; the [B,D,K,h,w] weight tensor of the reference is never materialised.  A scalar kernel
+// with the same arithmetic covers D % 4 != 0.
 #include <cstring>
 
 #include "pmn_common.hpp"
 
 struct AggArgs {
-    const float* cost;     // [B,D,h,w]
+    const float* cost;     // [B,h,w,D]
     const float* depth;    // [B,D,h,w]
-    const float* xnorm;    // [B,D,h,w]
+    const float* xnorm;    // [B,h,w,D]
     const float* fweight;  // [B,K,h,w]
     const float* offsets;  // [B,2K,h,w]
     float* score;          // [B,D,h,w]
@@ -67,9 +72,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     float smax = -__builtin_inff();
 #pragma unroll 1
     for (int d = dl; d < D; d += DL) {
-        const float* xp = a.xnorm + ((size_t)b * D + d) * hw;
-        const float* cp = a.cost + ((size_t)b * D + d) * hw;
-        const float xc = xp[p];
+        const float* xp = a.xnorm + (size_t)b * hw * D + d;  // hypothesis-last: pixel stride D
+        const float* cp = a.cost + (size_t)b * hw * D + d;
+        const float xc = xp[(size_t)p * D];
         float wk[KMAX], ck[KMAX];
         float wsum = 0.0f;
 #pragma unroll
@@ -77,10 +82,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
             wk[k] = 0.0f;
             ck[k] = 0.0f;
             if (k < K) {
-                const int o = off[k];
-                const float x1 =
-                    fmaf(xp[o + w + 1], w11[k], fmaf(xp[o + w], w10[k], fmaf(xp[o + 1], w01[k], xp[o] * w00[k])));
-                ck[k] = fmaf(cp[o + w + 1], w11[k], fmaf(cp[o + w], w10[k], fmaf(cp[o + 1], w01[k], cp[o] * w00[k])));
+                const size_t o = (size_t)off[k] * D, o1 = o + D, o2 = o + (size_t)w * D, o3 = o2 + D;
+                const float x1 = fmaf(xp[o3], w11[k], fmaf(xp[o2], w10[k], fmaf(xp[o1], w01[k], xp[o] * w00[k])));
+                ck[k] = fmaf(cp[o3], w11[k], fmaf(cp[o2], w10[k], fmaf(cp[o1], w01[k], cp[o] * w00[k])));
                 float t = fabsf(x1 - xc) / a.interval_scale;
                 t = fminf(fmaxf(t, 0.0f), 4.0f);
                 wk[k] = pmn_sigmoid(4.0f - 2.0f * t) * fw[k];
@@ -139,6 +143,125 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     a.depth_out[(size_t)b * hw + p] = out;
 }
 
+// ---- main kernel: D % 4 == 0, thread = (pixel, hypothesis quad) ------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regress_q4_kernel(const AggArgs a) {
+#pragma clang fp contract(off)
+    __shared__ float red[PMN_BLOCK];
+    const int h = a.h, w = a.w, hw = h * w, D = a.D, K = a.K, DQ = D >> 2;
+    const int npx = blockDim.x / DQ;  // host: blockDim.x = npx * DQ
+    const int px = threadIdx.x / DQ, q = threadIdx.x - px * DQ;
+    const int p_raw = blockIdx.x * npx + px;
+    const bool ok = p_raw < hw;
+    const int p = ok ? p_raw : hw - 1;  // out-of-range threads shadow the last pixel (no stores) so barriers stay uniform
+    const int b = blockIdx.y;
+    const int y = p / w, x = p - y * w;
+
+    int off[KMAX];
+    float w00[KMAX], w01[KMAX], w10[KMAX], w11[KMAX], fw[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        off[k] = 0;
+        w00[k] = w01[k] = w10[k] = w11[k] = fw[k] = 0.0f;
+        if (k < K) {
+            const float ox = a.offsets[((size_t)b * 2 * K + 2 * k) * hw + p];
+            const float oy = a.offsets[((size_t)b * 2 * K + 2 * k + 1) * hw + p];
+            float ix, iy;
+            pmn_neighbor_position((float)x, (float)y, a.table[2 * k], a.table[2 * k + 1], ox, oy, h, w, ix, iy);
+            const PmnTaps t = pmn_make_taps(ix, iy, h, w);
+            off[k] = t.off;
+            w00[k] = t.w00;
+            w01[k] = t.w01;
+            w10[k] = t.w10;
+            w11[k] = t.w11;
+            fw[k] = a.fweight[((size_t)b * K + k) * hw + p];
+        }
+    }
+
+    const float* xn = a.xnorm + (size_t)b * hw * D + 4 * q;
+    const float* cs = a.cost + (size_t)b * hw * D + 4 * q;
+    const float4 xc4 = *reinterpret_cast<const float4*>(xn + (size_t)p * D);
+    const float xc[4] = {xc4.x, xc4.y, xc4.z, xc4.w};
+    float wk[KMAX][4], ck[KMAX][4], wsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wk[k][j] = ck[k][j] = 0.0f;
+        if (k < K) {
+            const size_t o = (size_t)off[k] * D, o2 = o + (size_t)w * D;
+            const float4 xa = *reinterpret_cast<const float4*>(xn + o), xb = *reinterpret_cast<const float4*>(xn + o + D);
+            const float4 xcn = *reinterpret_cast<const float4*>(xn + o2), xd = *reinterpret_cast<const float4*>(xn + o2 + D);
+            const float4 ca = *reinterpret_cast<const float4*>(cs + o), cb = *reinterpret_cast<const float4*>(cs + o + D);
+            const float4 cc = *reinterpret_cast<const float4*>(cs + o2), cd = *reinterpret_cast<const float4*>(cs + o2 + D);
+            const float x00[4] = {xa.x, xa.y, xa.z, xa.w}, x01[4] = {xb.x, xb.y, xb.z, xb.w};
+            const float x10[4] = {xcn.x, xcn.y, xcn.z, xcn.w}, x11[4] = {xd.x, xd.y, xd.z, xd.w};
+            const float c00[4] = {ca.x, ca.y, ca.z, ca.w}, c01[4] = {cb.x, cb.y, cb.z, cb.w};
+            const float c10[4] = {cc.x, cc.y, cc.z, cc.w}, c11[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x1 = fmaf(x11[j], w11[k], fmaf(x10[j], w10[k], fmaf(x01[j], w01[k], x00[j] * w00[k])));
+                ck[k][j] = fmaf(c11[j], w11[k], fmaf(c10[j], w10[k], fmaf(c01[j], w01[k], c00[j] * w00[k])));
+                float t = fabsf(x1 - xc[j]) / a.interval_scale;
+                t = fminf(fmaxf(t, 0.0f), 4.0f);
+                wk[k][j] = pmn_sigmoid(4.0f - 2.0f * t) * fw[k];
+                wsum[j] = wsum[j] + wk[k][j];
+            }
+        }
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] = s[j] + ck[k][j] * (wk[k][j] / wsum[j]);
+        }
+
+    // exp(log_softmax) over the D hypotheses of the pixel: max, log-sum-exp, probabilities; then the regression
+    float smax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    red[threadIdx.x] = smax;
+    __syncthreads();
+    for (int i = 0; i < DQ; ++i) smax = fmaxf(smax, red[px * DQ + i]);
+    __syncthreads();
+    float esum = ((expf(s[0] - smax) + expf(s[1] - smax)) + expf(s[2] - smax)) + expf(s[3] - smax);
+    red[threadIdx.x] = esum;
+    __syncthreads();
+    esum = 0.0f;
+    for (int i = 0; i < DQ; ++i) esum = esum + red[px * DQ + i];
+    __syncthreads();
+    const float lse = logf(esum);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = 4 * q + j;
+        const size_t o = ((size_t)b * D + d) * hw + p;
+        const float prob = expf((s[j] - smax) - lse);
+        if (ok) a.score[o] = prob;
+        acc = acc + (a.is_inverse ? (float)d : a.depth[o]) * prob;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (q != 0 || !ok) return;
+    acc = 0.0f;
+    for (int i = 0; i < DQ; ++i) acc = acc + red[px * DQ + i];
+    float out = acc;
+    if (a.is_inverse) {
+        const float inv_min = 1.0f / a.depth[((size_t)b * D + (D - 1)) * hw + p];
+        const float inv_max = 1.0f / a.depth[((size_t)b * D) * hw + p];
+        const float inv = inv_max + acc / (float)(D - 1) * (inv_min - inv_max);
+        out = 1.0f / inv;
+    }
+    a.depth_out[(size_t)b * hw + p] = out;
+}
+
+template <int KMAX>
+static int launch_agg_q4(const AggArgs& a, hipStream_t s) {
+    const int DQ = a.D / 4, npx = PMN_BLOCK / DQ;
+    const dim3 grid((a.h * a.w + npx - 1) / npx, a.B), block(npx * DQ);
+    hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX>), grid, block, 0, s, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
 template <int KMAX, int DL>
 static int launch_agg_dl(const AggArgs& a, hipStream_t s) {
     constexpr int NPX = PMN_BLOCK / DL;
@@ -150,6 +273,10 @@ static int launch_agg_dl(const AggArgs& a, hipStream_t s) {
 
 template <int KMAX>
 static int launch_agg(const AggArgs& a, hipStream_t s) {
+    // 17 neighbours x (tap set + 4 weights + 4 costs) does not fit the register file: the scalar kernel takes those
+    if constexpr (KMAX <= 9) {
+        if (a.D % 4 == 0) return launch_agg_q4<KMAX>(a, s);
+    }
     if (a.D >= 32) return launch_agg_dl<KMAX, 16>(a, s);
     if (a.D >= 16) return launch_agg_dl<KMAX, 4>(a, s);
     return launch_agg_dl<KMAX, 1>(a, s);  // stage 1: 480k pixels already fill the chip (measured: DL=4 is slower)

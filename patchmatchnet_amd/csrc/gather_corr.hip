@@ -16,7 +16,7 @@
 //       item role   thread <-> (pixel, a few hypotheses): projects the items and parks {texel offset, 4 corner
 //                   weights} in LDS (phase A: the projection is done once per item, not once per lane); later runs
 //                   the pointwise MLPs on its items (weights broadcast from LDS, each weight row reused for all the
-//                   thread's items) and stores cost[d][pixel] coalesced;
+//                   thread's items) and stores cost[pixel][d] (hypothesis-last, what pmn_aggregate_regress gathers);
 //       lane role   LPI lanes <-> pixel: walk the pixel's hypotheses (phase B): LDS broadcast of the record,
 //                   4 x global_load_dwordx4, bilinear blend, product with the register-resident reference quad,
 //                   in-lane + one DPP step group reduction.  With known view weights the per-(pixel,group,d)
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
 #pragma unroll
                     for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = x[j][g];
                 }
-                a.out[((size_t)b * D + d) * hw + pA] = o[j];
+                a.out[((size_t)b * hw + pA) * D + d] = o[j];  // cost is hypothesis-last [B,h,w,D]
             }
         }
         return;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
 #pragma unroll
                 for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = ssum[j][g];
             }
-            a.out[((size_t)b * D + d) * hw + pA] = o[j];
+            a.out[((size_t)b * hw + pA) * D + d] = o[j];  // cost is hypothesis-last [B,h,w,D]
         }
     }
 }

@@ -17,7 +17,7 @@ struct HypArgs {
     const float* depth_max;  // [B]
     const float* offsets;    // [B,2K,h,w] or null
     float* depth_sample;     // [B,D,h,w]
-    float* xnorm;            // [B,D,h,w]
+    float* xnorm;            // [B,h,w,D]
     int depth_shift, num_sample, K, B, h, w;
     float interval_scale;
     int table[2 * PMN_MAX_NEIGHBORS];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_kernel(const HypArg
         if (j < D) {
             const size_t o = ((size_t)b * D + j) * hw + p;
             a.depth_sample[o] = v[j];
-            a.xnorm[o] = (1.0f / v[j] - inv_max) / range;
+            a.xnorm[((size_t)b * hw + p) * D + j] = (1.0f / v[j] - inv_max) / range;  // hypothesis-last [B,h,w,D]
         }
     }
 }

@@ -48,6 +48,16 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def _dlast(t: torch.Tensor, name: str) -> torch.Tensor:
+    """[B,D,h,w] tensor whose STORAGE is hypothesis-last [B,h,w,D] (what pmn_init_hypotheses / pmn_warp_correlate write and
+    pmn_aggregate_regress reads); a planar tensor (tests, oracle data) is re-laid-out here."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise PmnError(f"{name}: expected a float32 tensor on a ROCm GPU (no CPU fallback)")
+    if t.permute(0, 2, 3, 1).is_contiguous():
+        return t
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -136,7 +146,7 @@ def init_hypotheses(noise: Optional[torch.Tensor], depth: Optional[torch.Tensor]
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
     """DepthInitialization + Propagation (reference models/patchmatch.py:53-94, 115-124).
 
-    Returns (depth_sample [B,D,h,w], xnorm [B,D,h,w])."""
+    Returns (depth_sample [B,D,h,w], xnorm [B,D,h,w] -- a hypothesis-last view: storage [B,h,w,D])."""
     _dev(depth_min, "depth_min")
     _dev(depth_max, "depth_max")
     B = depth_min.shape[0]
@@ -165,7 +175,7 @@ def init_hypotheses(noise: Optional[torch.Tensor], depth: Optional[torch.Tensor]
         tab, tab_p = _host_i32(table, 2 * K, "table")
     D = D0 + K
     ds = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
-    xn = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    xn = torch.empty((B, h, w, D), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
     with torch.cuda.device(dev):
         check(_lib.lib().pmn_init_hypotheses(_ptr(noise), _ptr(depth) if noise is None else None, depth_shift,
                                              depth_min.data_ptr(), depth_max.data_ptr(), num_sample,
@@ -181,7 +191,7 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
                    want_argmax: bool = False):
     """The fused warp + gather + group-correlation + view aggregation + SimilarityNet-MLP kernel.
 
-    Returns (cost [B,D,h,w], view_weights [B,N,h,w] (input passed through, or computed), argmax or None,
+    Returns (cost [B,D,h,w] (a hypothesis-last view: storage [B,h,w,D]), view_weights [B,N,h,w] (input passed through, or computed), argmax or None,
     aggregated similarity [B,G,D,h,w] or None)."""
     _dev(ref_nhwc, "ref_nhwc")
     _dev(src_nhwc, "src_nhwc")
@@ -206,7 +216,7 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
         vw_out = torch.empty((B, N, h, w), dtype=torch.float32, device=dev)
         if want_argmax:
             argmax = torch.empty((B, N, h, w), dtype=torch.int32, device=dev)
-    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    cost = torch.empty((B, h, w, D), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)  # hypothesis-last storage
     sim = torch.empty((B, G, D, h, w), dtype=torch.float32, device=dev) if want_similarity else None
     with torch.cuda.device(dev):
         if _TIMING is not None:
@@ -227,9 +237,9 @@ def aggregate_regress(cost: torch.Tensor, depth_sample: torch.Tensor, xnorm: tor
                       eval_offsets: torch.Tensor, table: np.ndarray, interval_scale: float, is_inverse: bool
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Adaptive spatial aggregation + softmax + regression -> (score [B,D,h,w], depth [B,h,w])."""
-    for n, t in (("cost", cost), ("depth_sample", depth_sample), ("xnorm", xnorm), ("feature_weight", feature_weight_),
-                 ("eval_offsets", eval_offsets)):
+    for n, t in (("depth_sample", depth_sample), ("feature_weight", feature_weight_), ("eval_offsets", eval_offsets)):
         _dev(t, n)
+    cost, xnorm = _dlast(cost, "cost"), _dlast(xnorm, "xnorm")
     B, D, h, w = cost.shape
     K = feature_weight_.shape[1]
     if tuple(depth_sample.shape) != (B, D, h, w) or tuple(xnorm.shape) != (B, D, h, w) or \
