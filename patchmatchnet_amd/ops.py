@@ -19,11 +19,19 @@ from ._lib import PmnError, check
 # When enabled, every pmn_warp_correlate launch is bracketed by HIP events recorded on the launch stream (torch's
 # current stream) and tagged with its ALGORITHMIC byte count B_alg = 4*h*w*[(1+N)*C + D + N + G*D].
 _TIMING = None
+_TIMING_ON = True
 
 
 def enable_kernel_timing() -> None:
-    global _TIMING
-    _TIMING = []
+    global _TIMING, _TIMING_ON
+    _TIMING, _TIMING_ON = [], True
+
+
+def pause_kernel_timing(paused: bool) -> None:
+    """Suspends / resumes recording without dropping what was recorded (an event pair costs ~10 us of stream time on
+    ROCm, so bench.py samples every few steps instead of bracketing every launch)."""
+    global _TIMING_ON
+    _TIMING_ON = not paused
 
 
 def disable_kernel_timing():
@@ -219,14 +227,14 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
     cost = torch.empty((B, h, w, D), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)  # hypothesis-last storage
     sim = torch.empty((B, G, D, h, w), dtype=torch.float32, device=dev) if want_similarity else None
     with torch.cuda.device(dev):
-        if _TIMING is not None:
+        if _TIMING is not None and _TIMING_ON:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         check(_lib.lib().pmn_warp_correlate(ref_nhwc.data_ptr(), src_nhwc.data_ptr(), rel_proj.data_ptr(),
                                             depth_sample.data_ptr(), _ptr(view_weights), vw_shift, sim_p, pix_p, B, N, C,
                                             G, D, h, w, hs, ws, cost.data_ptr(), _ptr(vw_out), _ptr(argmax), _ptr(sim),
                                             _stream(cost)), "pmn_warp_correlate")
-        if _TIMING is not None:
+        if _TIMING is not None and _TIMING_ON:
             ev1.record()
             _TIMING.append((ev0, ev1, 4 * B * h * w * ((1 + N) * C + D + N + G * D),
                             f"C{C}_D{D}_{h}x{w}_N{N}_{'vw' if view_weights is not None else 'pixelwise'}"))
