@@ -97,9 +97,10 @@ def main():
             K = 9
             eval_off = (0.5 * torch.randn(1, 2 * K, h, w, generator=gen)).to(dev)
             fw = torch.rand(1, K, h, w, generator=gen).to(dev)
-            cost = torch.randn(1, D, h, w, generator=gen).to(dev)
-            xn = ((1.0 / hyp) - 1 / 935.0) / (1 / 425.0 - 1 / 935.0)
-            med, mn = timed(lambda: ops.aggregate_regress(cost, hyp, xn.contiguous(), fw, eval_off, pm._etable,
+            # cost / xnorm hypothesis-last, as pmn_warp_correlate / pmn_init_hypotheses hand them over
+            cost = torch.randn(1, h, w, D, generator=gen).to(dev).permute(0, 3, 1, 2)
+            xn = (((1.0 / hyp) - 1 / 935.0) / (1 / 425.0 - 1 / 935.0)).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            med, mn = timed(lambda: ops.aggregate_regress(cost, hyp, xn, fw, eval_off, pm._etable,
                                                           pm.patchmatch_interval_scale, stage == 1), args.reps)
             rows.append((f"aggregate_regress s{stage} D{D} x{count}", med, mn, 0.0))
             med, mn = timed(lambda: ops.feature_weight(ref_nhwc, eval_off, pm._etable,
