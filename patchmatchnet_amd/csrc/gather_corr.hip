@@ -139,12 +139,16 @@ __device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
 // DPP row_newbcast for 16-lane groups (one VALU op, no LDS), ds_bpermute for 8-lane groups.
 template <int LPI, int SL>
 __device__ __forceinline__ int group_bcast_i(int v) {
+    // mov_dpp (bound_ctrl set): one instruction; update_dpp with an `old` operand costs a v_mov to initialise the destination
     if constexpr (LPI == 4) {
-        return __builtin_amdgcn_update_dpp(0, v, SL | (SL << 2) | (SL << 4) | (SL << 6), 0xF, 0xF, false);
+        return __builtin_amdgcn_mov_dpp(v, SL | (SL << 2) | (SL << 4) | (SL << 6), 0xF, 0xF, true);
     } else if constexpr (LPI == 16) {
-        return __builtin_amdgcn_update_dpp(0, v, 0x150 + SL, 0xF, 0xF, false);
+        return __builtin_amdgcn_mov_dpp(v, 0x150 + SL, 0xF, 0xF, true);
     } else {
-        return __shfl(v, (int)((threadIdx.x & 63u) & ~(unsigned)(LPI - 1)) + SL, 64);
+        // 8-lane groups = the two halves of a 16-lane DPP row: row_newbcast of lane SL into banks 0-1 (lanes 0..7 of the
+        // row), of lane 8+SL into banks 2-3 (lanes 8..15) -- two VALU ops instead of a ds_bpermute LDS round trip
+        const int lo = __builtin_amdgcn_update_dpp(v, v, 0x150 + SL, 0xF, 0x3, false);
+        return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + SL, 0xF, 0xC, false);
     }
 }
 template <int LPI, int SL>
@@ -175,6 +179,38 @@ __device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, co
     hi = __builtin_elementwise_fma(pmn_f2{t10.z, t10.w}, wc, hi);
     lo = __builtin_elementwise_fma(pmn_f2{t11.x, t11.y}, wd, lo);
     hi = __builtin_elementwise_fma(pmn_f2{t11.z, t11.w}, wd, hi);
+    float s = fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
+    if (LPG == 2) s += pmn_pair_swap(s);
+    return s * (1.0f / CG);
+}
+
+// The same item in two halves, so a batch of items can have ALL its corner loads in flight before the first blend (left to
+// itself hipcc schedules load -> wait -> blend item by item).  `sbase` is the wave-uniform base of the view's map (SGPR pair),
+// `bo` the 32-bit byte offset of this lane's channel quad of the north-west texel: the loads use the SGPR-base + VGPR-offset
+// form, east corner through the immediate offset field (no 64-bit VALU address arithmetic).
+struct PmnCorners { float4 t00, t01, t10, t11; };
+
+template <int C>
+__device__ __forceinline__ PmnCorners load_corners(const char* __restrict__ sbase, const unsigned bo, const unsigned row_bytes) {
+    PmnCorners c;
+    c.t00 = *reinterpret_cast<const float4*>(sbase + bo);
+    c.t01 = *reinterpret_cast<const float4*>(sbase + bo + C * 4);
+    c.t10 = *reinterpret_cast<const float4*>(sbase + (bo + row_bytes));
+    c.t11 = *reinterpret_cast<const float4*>(sbase + (bo + row_bytes) + C * 4);
+    return c;
+}
+
+template <int LPG, int CG>
+__device__ __forceinline__ float blend_corners(const PmnCorners& c, const float4 w4, const float4 refq) {
+    const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
+    pmn_f2 lo = pmn_f2{c.t00.x, c.t00.y} * wa;
+    pmn_f2 hi = pmn_f2{c.t00.z, c.t00.w} * wa;
+    lo = __builtin_elementwise_fma(pmn_f2{c.t01.x, c.t01.y}, wb, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{c.t01.z, c.t01.w}, wb, hi);
+    lo = __builtin_elementwise_fma(pmn_f2{c.t10.x, c.t10.y}, wc, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{c.t10.z, c.t10.w}, wc, hi);
+    lo = __builtin_elementwise_fma(pmn_f2{c.t11.x, c.t11.y}, wd, lo);
+    hi = __builtin_elementwise_fma(pmn_f2{c.t11.z, c.t11.w}, wd, hi);
     float s = fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
     if (LPG == 2) s += pmn_pair_swap(s);
     return s * (1.0f / CG);
@@ -341,16 +377,24 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
                 rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
                 roff[j] = t.off;
             }
-            const float4* srcv = reinterpret_cast<const float4*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * LPI + lc;
+            const char* sbase = reinterpret_cast<const char*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * (C * 4);
+            const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
             const float vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
+            // Batches of NB items: records broadcast + all 4*NB corner loads issued, THEN the NB blends; the fences keep hipcc
+            // from re-serialising each item (load -> wait -> blend) or hoisting every load of the unrolled loop (spills).
+            constexpr int NB = 2;  // measured: 4 (at 3 waves/SIMD) is no faster on the cascade's hypotheses
+            static_assert(DT % NB == 0, "hypothesis bound is a multiple of the batch");
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                if (EXACT || d < D) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    float4 w4;
-                    int off;
-                    // compile-time (j, source lane) of hypothesis d
+            for (int d0 = 0; d0 < DT; d0 += NB) {
+                PmnCorners cn[NB];
+                float4 wq[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (EXACT || d < D) {
+                        float4 w4;
+                        int off;
+                        // compile-time (j, source lane) of hypothesis d
 #define PMN_BCAST_CASE(SL)                                                    \
     case SL:                                                                  \
         w4.x = group_bcast_f<LPI, SL>(rw00[d / LPI]);                         \
@@ -359,20 +403,25 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         w4.w = group_bcast_f<LPI, SL>(rw11[d / LPI]);                         \
         off = group_bcast_i<LPI, SL>(roff[d / LPI]);                          \
         break;
-                    switch (d % LPI) {
-                        PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
-                        PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
-                        PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
-                        PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
-                        default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
-                    }
+                        switch (d % LPI) {
+                            PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
+                            PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
+                            PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
+                            PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
+                            default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
+                        }
 #undef PMN_BCAST_CASE
-                    const float s = gather_item<LPI, LPG, CG>(srcv, w4, off, ws, refq);
-                    acc[d] = mul_add_unfused(acc[d], s, vw);
+                        wq[i] = w4;
+                        cn[i] = load_corners<C>(sbase, (unsigned)off * (C * 4) + lane_bytes, row_bytes);
+                    }
                 }
-                // keep at most 4 items (16 x dwordx4) in flight: without the fence the scheduler hoists every load
-                // of the unrolled loop and the register allocator spills
-                if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (EXACT || d < D) acc[d] = mul_add_unfused(acc[d], blend_corners<LPG, CG>(cn[i], wq[i], refq), vw);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (owner) {
