@@ -134,7 +134,9 @@ int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float
  * [K*K][cin/8][coutp/32][64][4] with coutp = cout rounded up to 32 (patchmatchnet_amd/params.py: pack_conv_mfma); shift
  * DEVICE float[coutp].
  *   planar == 0  FeatureNet's wide layers conv5..conv10 (reference models/net.py:25-34): out [N,Ho,Wo,cout] channels-last,
- *                out_b NULL, ca == cout, dil 1; supported (cin,cout,K,stride): (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2)
+ *                out_b NULL, ca == cout, dil 1; supported (cin,cout,K,stride): (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2);
+ *                plus the 1x1 form (64, cout <= 128, 1, 1) with channels [0,ca) -> out [N,H,W,ca], [ca,cout) -> out_b [N,H,W,cout-ca]
+ *                (the 1/8-resolution level of the folded FPN head, same arithmetic as pmn_fpn_level)
  *   planar == 1  the offset heads propa_conv + eval_conv of one stage as ONE dilated 3x3 convolution over the reference feature
  *                (models/patchmatch.py:288-311): channels [0,ca) -> out [N,ca,Ho,Wo], [ca,cout) -> out_b [N,cout-ca,Ho,Wo]
  *                (NULL when ca == cout), both planar; K 3, stride 1, pad == dil; supported (cin,dil): (64,2), (32,4), (16,6),

@@ -434,7 +434,7 @@ extern "C" int pmn_stem(const float* img, const float* w0, const float* s0, cons
 // leaves registers: a thread owns one pixel, builds the 64 intermediate channels in two halves of 32 (up-sampling taps
 // + SGPR-weight FMAs) and folds each half straight into the 16 outputs.
 template <int CIN, int CMID, int COUT>
-__global__ __launch_bounds__(PMN_BLOCK, 4) void fpn_tail_kernel(const float* __restrict__ x, const float* __restrict__ up,
+__global__ __launch_bounds__(PMN_BLOCK, 2) void fpn_tail_kernel(const float* __restrict__ x, const float* __restrict__ up,
                                                               const float* __restrict__ w_in,
                                                               const float* __restrict__ b_in,
                                                               const float* __restrict__ w_out, float* __restrict__ out,
@@ -714,15 +714,18 @@ __global__ __launch_bounds__(PMN_BLOCK) void deconv3x3s2_kernel(const float* __r
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
-#pragma unroll
+    // tap loops rolled: fully unrolled, the 576 wave-uniform weights are hoisted into SGPRs at once and spilled through
+    // v_readlane / v_writelane (706 of them)
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
         const int ty = oy + 1 - ky;
         const bool yok = ty >= 0 && !(ty & 1) && (ty >> 1) < Hi;
-#pragma unroll
+#pragma unroll 1
         for (int kx = 0; kx < 3; ++kx) {
             const int tx = ox + 1 - kx;
             const bool ok = yok && tx >= 0 && !(tx & 1) && (tx >> 1) < Wi;
             const float* ip = in + (((size_t)n * Hi + (ok ? (ty >> 1) : 0)) * Wi + (ok ? (tx >> 1) : 0)) * CIN;
+            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * CIN * COUT);
             float v[CIN];
 #pragma unroll
             for (int c = 0; c < CIN; c += 4) {
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void deconv3x3s2_kernel(const float* __r
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[ci], wt[((ky * 3 + kx) * CIN + ci) * COUT + c], acc[c]);
+                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[ci], wq[ci * COUT + c], acc[c]);
         }
     }
 #pragma unroll

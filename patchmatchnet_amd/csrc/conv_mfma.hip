@@ -159,9 +159,15 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __re
             }
         }
     } else {
+        // channels-last: channels [0,ca) -> out (pitch ca), [ca,cout) -> out_b (pitch cout-ca); ca == cout == COUT for the plain layers
+        const int cb = a.cout - a.ca;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float sh = shift[t * 32 + li];
+            const int co = t * 32 + li;
+            const float sh = shift[co];
+            float* dst = co < a.ca ? out + co : out_b + (co - a.ca);
+            const int pitch = co < a.ca ? a.ca : cb;
+            const bool live = co < a.cout;
 #pragma unroll
             for (int g = 0; g < PG; ++g) {
 #pragma unroll
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_mfma_kernel(const float* __re
                     const int oy = oy0 + (wave * PG + g) * 2 + (row >> 4), ox = ox0 + (row & 15);
                     float v = acc[g][t][r] + sh;
                     if (a.relu) v = fmaxf(v, 0.0f);
-                    if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + t * 32 + li] = v;
+                    if (live && oy < a.Ho && ox < a.Wo) dst[(((size_t)n * a.Ho + oy) * a.Wo + ox) * pitch] = v;
                 }
             }
         }
@@ -197,7 +203,8 @@ static int launch_mfma(const float* in, const float* w, const float* shift, floa
 // in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][coutp/32][64][4] (params.pack_conv_mfma; coutp = cout rounded
 // up to 32, BatchNorm scale folded in); shift DEVICE float[coutp].
 //   planar == 0: out [N,Ho,Wo,cout] channels-last (out_b NULL, ca == cout == coutp, dil == 1); supported (cin,cout,K,stride):
-//                (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2)
+//                (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2); and (64, <=128, 1, 1) with the channels split between
+//                out [N,H,W,ca] and out_b [N,H,W,cout-ca]
 //   planar == 1: out [N,ca,Ho,Wo] and out_b [N,cout-ca,Ho,Wo] (NULL when ca == cout) planar; K = 3, stride 1, pad == dil;
 //                supported (cin,dil): (64,2), (32,4), (16,6) with cout <= 64 -- the offset heads of the default cascade
 extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const float* shift, float* out, float* out_b, int N,
@@ -213,7 +220,11 @@ extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const floa
     if (a.Ho < 1 || a.Wo < 1) return PMN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (!planar) {
-        if (dil != 1 || ca != cout) return PMN_ERR_SHAPE;
+        if (dil != 1) return PMN_ERR_SHAPE;
+        // 1x1, 64 -> (ca | cout-ca) <= 128 channels: the 1/8-resolution level of the folded FPN head (pmn_fpn_level's arithmetic)
+        if (cin == 64 && K == 1 && stride == 1 && pad == 0 && cout <= 128)
+            return launch_mfma<64, 64, 128, 1, 1, 1, 4, 1, 4, false>(in, weights, shift, out, out_b, a, st);
+        if (ca != cout) return PMN_ERR_SHAPE;
 #define PMN_MFMA(CI, CCH, CO, KK, SS, NWV, PGV, DD) return launch_mfma<CI, CCH, CO, KK, SS, 1, NWV, PGV, DD, false>(in, weights, shift, out, out_b, a, st)
         if (cin == 64 && cout == 64 && K == 3 && stride == 1) PMN_MFMA(64, 32, 64, 3, 1, 2, 2, 4);
         if (cin == 32 && cout == 32 && K == 3 && stride == 1) PMN_MFMA(32, 32, 32, 3, 1, 4, 2, 4);

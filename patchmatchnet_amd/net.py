@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -67,6 +68,9 @@ class FeatureNet(nn.Module):
                                    self.inner2.bias, self.output2.weight, self.output3.weight)
             for lvl, (w, b) in fold.items():
                 pk[f"fpn{lvl}"] = (torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev))
+            w8 = torch.from_numpy(np.ascontiguousarray(fold[8][0].T))[:, :, None, None]  # [112,64,1,1]: matrix-core form of level 1/8
+            w, s = params.pack_conv_mfma(w8, bias=torch.from_numpy(fold[8][1]))
+            pk["fpn8_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -95,7 +99,10 @@ class FeatureNet(nn.Module):
         if self.fold_fpn:
             # the FPN head is linear: its 1x1 convolutions are composed on the host (params.fold_fpn) and each level is one
             # bandwidth-bound kernel -- the 64-channel intermediates at 1/4 and 1/2 resolution never exist
-            f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)
+            if self.mfma_convs:  # 64 -> 112 channels: a GEMM, on the matrix cores
+                f3, u8 = ops.pointwise_split_mfma(eighth, *pk["fpn8_mfma"], cout=112, ca=64)
+            else:
+                f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)
             f2, u4 = ops.fpn_level(quarter, u8, *pk["fpn4"], ca=32)
             f1, _ = ops.fpn_level(half, u4, *pk["fpn2"], ca=16)
             return {3: f3, 2: f2, 1: f1}

@@ -390,6 +390,24 @@ def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: 
     return out
 
 
+def pointwise_split_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int):
+    """pmn_conv2d_mfma, 1x1 form: out = x @ W + shift on the matrix cores with the output channels split between two
+    channels-last tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights from
+    params.pack_conv_mfma of the [cout,64,1,1] filter -> ([N,H,W,ca], [N,H,W,cout-ca])."""
+    for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    coutp = shift.shape[0]
+    if tuple(weights.shape) != (1, cin // 8, coutp // 32, 64, 4) or not 0 < ca < cout <= coutp:
+        raise PmnError("pointwise_split_mfma: weights are not in pack_conv_mfma layout for this input")
+    out_a = torch.empty((N, H, W, ca), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((N, H, W, cout - ca), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d_mfma(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out_a.data_ptr(), out_b.data_ptr(),
+                                         N, H, W, cin, cout, ca, 1, 1, 0, 1, 0, 0, _stream(x)), "pmn_conv2d_mfma")
+    return out_a, out_b
+
+
 def offset_heads_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int, dil: int):
     """pmn_conv2d_mfma (planar = 1): the offset heads of one stage (propa_conv rows first, then eval_conv; reference
     models/patchmatch.py:288-311) as one dilated 3x3 convolution with bias; x [N,H,W,cin] channels-last, weights from

@@ -308,6 +308,23 @@ def test_offset_heads_mfma_against_torch(cin, dil, n_p, n_e, H, W, N):
         assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
 
 
+def test_fpn_level8_matrix_core_form_matches_valu_form():
+    """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 19, 27, 64, generator=gen)
+    wt = 0.2 * torch.randn(112, 64, generator=gen)
+    bias = 0.1 * torch.randn(112, generator=gen)
+    ref = torch.einsum("nhwc,dc->nhwd", x.double(), wt.double()) + bias.double()
+    w, sh = PP.pack_conv_mfma(wt[:, :, None, None], bias=bias)
+    a, b = P.ops.pointwise_split_mfma(x.to(DEV), torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), cout=112, ca=64)
+    a2, b2 = P.ops.fpn_level(x.to(DEV), None, wt.t().contiguous().to(DEV), bias.to(DEV), ca=64)
+    assert tuple(a.shape) == (3, 19, 27, 64) and tuple(b.shape) == (3, 19, 27, 48)
+    for got, want in ((a, ref[..., :64]), (b, ref[..., 64:]), (a2, ref[..., :64]), (b2, ref[..., 64:])):
+        assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_featurenet_hip_matches_miopen(fold):
     """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels, with the FPN
