@@ -226,10 +226,12 @@ extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const floa
             return launch_mfma<64, 64, 128, 1, 1, 1, 4, 1, 4, false>(in, weights, shift, out, out_b, a, st);
         if (ca != cout) return PMN_ERR_SHAPE;
 #define PMN_MFMA(CI, CCH, CO, KK, SS, NWV, PGV, DD) return launch_mfma<CI, CCH, CO, KK, SS, 1, NWV, PGV, DD, false>(in, weights, shift, out, out_b, a, st)
-        if (cin == 64 && cout == 64 && K == 3 && stride == 1) PMN_MFMA(64, 32, 64, 3, 1, 2, 2, 4);
-        if (cin == 32 && cout == 32 && K == 3 && stride == 1) PMN_MFMA(32, 32, 32, 3, 1, 4, 2, 4);
-        if (cin == 32 && cout == 64 && K == 5 && stride == 2) PMN_MFMA(32, 8, 64, 5, 2, 2, 2, 5);
-        if (cin == 16 && cout == 32 && K == 5 && stride == 2) PMN_MFMA(16, 8, 32, 5, 2, 2, 2, 5);
+        // NW = 4 waves x one 32-pixel group each (8x16-pixel tiles): one wave per SIMD per workgroup, 80-128 VGPRs; measured
+        // 13-20 % faster than 2 waves x 2 groups on the 64-column layers and the stride-2 layers (profiles/README.md)
+        if (cin == 64 && cout == 64 && K == 3 && stride == 1) PMN_MFMA(64, 64, 64, 3, 1, 4, 1, 4);
+        if (cin == 32 && cout == 32 && K == 3 && stride == 1) PMN_MFMA(32, 32, 32, 3, 1, 4, 1, 4);
+        if (cin == 32 && cout == 64 && K == 5 && stride == 2) PMN_MFMA(32, 16, 64, 5, 2, 4, 1, 5);
+        if (cin == 16 && cout == 32 && K == 5 && stride == 2) PMN_MFMA(16, 8, 32, 5, 2, 4, 1, 5);
 #undef PMN_MFMA
         return PMN_ERR_SHAPE;
     }
