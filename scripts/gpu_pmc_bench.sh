@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC passes over a short bench run: per-kernel SQ counters for every kernel of the forward (development aid).
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench
+rm -rf $OUT; mkdir -p $OUT
+i=0
+while read -r line; do
+  [ -z "$line" ] && continue
+  i=$((i+1))
+  (cd /tmp && timeout 400 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/p$i.log 2>&1)
+done <<LIST
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
+SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAIT_ANY
+LIST
+python - <<'PY'
+import csv,glob,collections,os
+out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_bench'
+agg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(out+'/p*/*counter_collection.csv')):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name']
+        if k.startswith('void at::') or 'rocclr' in k: continue
+        agg[k[:64]][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(out+'/summary.txt','w') as fo:
+    for key,cs in agg.items():
+        g=lambda n: (sum(cs[n])/len(cs[n])) if n in cs else 0.0
+        cyc=g('GRBM_GUI_ACTIVE')/8.0
+        line='%-66s cyc %8.0f  valu_busy %4.0f%%  valu/wave %6.0f  lds_busy %4.0f%%  lds_conf %4.0f%%  wait_inst %4.0f%%  smem/wave %5.0f\n'%(
+            key, cyc, 100*g('SQ_ACTIVE_INST_VALU')*4/1024/max(cyc,1), g('SQ_INSTS_VALU')/max(g('SQ_WAVES'),1),
+            100*g('SQ_LDS_IDX_ACTIVE')/256/max(cyc,1), 100*g('SQ_LDS_BANK_CONFLICT')/max(g('SQ_LDS_IDX_ACTIVE'),1),
+            100*g('SQ_WAIT_INST_ANY')/max(g('SQ_WAVE_CYCLES'),1), g('SQ_INSTS_SMEM')/max(g('SQ_WAVES'),1))
+        print(line,end=''); fo.write(line)
+PY
