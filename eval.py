@@ -24,8 +24,8 @@ from torch.utils.data import DataLoader
 import patchmatchnet_amd as P
 from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
-from patchmatchnet_amd.data_io import read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
-from patchmatchnet_amd.mvs import MVSDataset
+from patchmatchnet_amd.data_io import image_shape, read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
+from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
 
 
 def print_args(args) -> None:
@@ -53,50 +53,88 @@ def load_model(args, device):
     return model.to(device).eval()
 
 
+def _write_maps(args, sample, depth, confidence, produced):
+    depth_np = depth.detach().cpu().numpy()
+    conf_np = confidence.detach().cpu().numpy()
+    for b, filename in enumerate(sample["filename"]):
+        for kind, arr in (("depth_est", depth_np[b, 0]), ("confidence", conf_np[b])):
+            path = os.path.join(args.output_folder, filename.format(kind, args.file_format))
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            save_map(path, np.ascontiguousarray(arr))
+        scan = filename.split("{}")[0].rstrip(os.sep)
+        produced[(scan, int(sample["ref_view"][b]))] = torch.stack((depth[b, 0], confidence[b]), 0)
+
+
+def _encode_once_ok(dataset, scan, light, views):
+    """The encode-once path needs every view of the group at one size that FeatureNet takes as is (multiples of 8: otherwise
+    PatchmatchNet.forward resizes per sample, reference models/net.py:304-318, and the plain path reproduces that)."""
+    shapes = {image_shape(dataset.image_path(scan, light, v), dataset.max_dim)[:2] for v in views}
+    if len(shapes) != 1:
+        return False
+    h, w = next(iter(shapes))
+    return h % 8 == 0 and w % 8 == 0
+
+
 def save_depth(args, rank, world, device):
-    """Runs the network over this rank's reference views and writes depth / confidence maps (reference eval.py:20-82)."""
+    """Runs the network over this rank's reference views and writes depth / confidence maps (reference eval.py:20-82).
+
+    Per-scan feature cache: every image of a scan is a source view of ~num_views other samples,
+    and the reference decodes AND re-encodes it each time.  With --feature_cache > 0 a (scan, light) group is processed in two
+    passes: every view the rank's samples read is decoded once and pushed through FeatureNet once (its pyramid, 53 MB per
+    1600x1200 view, stays on the device, channels-last); then the samples are run from their cameras alone.  Same maps, bit for
+    bit, as the plain path (tests/test_eval_gpu.py)."""
     model = load_model(args, device)
     dataset = MVSDataset(data_path=args.input_folder, num_views=args.num_views, max_dim=args.image_max_dim,
                          scan_list=args.scan_list, num_light_idx=args.num_light_idx).shard(rank, world)
-    loader = DataLoader(dataset=dataset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                        drop_last=False)
     produced = {}  # (scan, ref view) -> [2,H,W] on device, kept for the per-scan gather
-    # Per-scan feature cache (SURVEY.md 8(f) row 1): every image of a scan is a source view of ~num_views other samples, and
-    # the reference re-encodes it each time.  Feature pyramids (53 MB per 1600x1200 view, channels-last, on the device) are
-    # kept per (scan, light, view) in an LRU of --feature_cache entries; only the views missing from it go through FeatureNet.
-    cache = collections.OrderedDict()
-    use_cache = args.feature_cache > 0 and args.batch_size == 1
+    done, total = 0, len(dataset)
     with torch.no_grad():
-        for batch_idx, sample in enumerate(loader):
+        for (scan, light), indices in dataset.groups().items():
+            views = dataset.views_of(indices)
+            encode_once = args.feature_cache > 0 and args.batch_size == 1 and _encode_once_ok(dataset, scan, light, views)
+            subset = torch.utils.data.Subset(dataset, indices)
+            if not encode_once:
+                dataset.load_images = True
+                loader = DataLoader(subset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
+                                    drop_last=False)
+                for sample in loader:
+                    start = time.time()
+                    depth, confidence, _ = model([im.to(device) for im in sample["images"]], sample["intrinsics"].to(device),
+                                                 sample["extrinsics"].to(device), sample["depth_min"].to(device),
+                                                 sample["depth_max"].to(device))
+                    _write_maps(args, sample, depth, confidence, produced)
+                    done += len(sample["filename"])
+                    print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
+                continue
+            # pass 1: decode + encode every view once (FeatureNet in batches of up to 4 images)
             start = time.time()
-            images = [im.to(device) for im in sample["images"]]
-            features = None
-            if use_cache and all(im.shape == images[0].shape for im in images) and \
-                    images[0].shape[2] % 8 == 0 and images[0].shape[3] % 8 == 0:
-                keys = [(sample["scan"][0], sample["light"][0], int(v), tuple(images[0].shape[2:]))
-                        for v in sample["view_ids"][0]]
-                missing = [i for i, k in enumerate(keys) if k not in cache]
-                if missing:
-                    f = model.feature.forward_hip([images[i] for i in missing])
-                    for j, i in enumerate(missing):
-                        cache[keys[i]] = {s: t[j:j + 1] for s, t in f.items()}
-                for k in keys:
-                    cache.move_to_end(k)
-                features = [{s: t.permute(0, 3, 1, 2) for s, t in cache[k].items()} for k in keys]
-                while len(cache) > args.feature_cache:
-                    cache.popitem(last=False)
-            depth, confidence, _ = model(images, sample["intrinsics"].to(device), sample["extrinsics"].to(device),
-                                         sample["depth_min"].to(device), sample["depth_max"].to(device), features=features)
-            depth_np = depth.detach().cpu().numpy()
-            conf_np = confidence.detach().cpu().numpy()
-            print("Iter {}/{}, time = {:.3f}".format(batch_idx + 1, len(loader), time.time() - start))
-            for b, filename in enumerate(sample["filename"]):
-                for kind, arr in (("depth_est", depth_np[b, 0]), ("confidence", conf_np[b])):
-                    path = os.path.join(args.output_folder, filename.format(kind, args.file_format))
-                    os.makedirs(os.path.dirname(path), exist_ok=True)
-                    save_map(path, np.ascontiguousarray(arr))
-                scan = filename.split("{}")[0].rstrip(os.sep)
-                produced[(scan, int(sample["ref_view"][b]))] = torch.stack((depth[b, 0], confidence[b]), 0)
+            pyramids, images = {}, {}
+            refs = {dataset.metas[i][2] for i in indices}
+            vloader = DataLoader(MVSViewDataset(dataset, scan, light, views), batch_size=4, shuffle=False,
+                                 num_workers=args.num_workers, drop_last=False)
+            for batch in vloader:
+                imgs = batch["image"].to(device)
+                f = model.feature.forward_hip(imgs)
+                for j, v in enumerate(batch["view"].tolist()):
+                    pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
+                    if v in refs:
+                        images[v] = imgs[j:j + 1]  # Refinement reads the reference image
+            print("{}{}: {} views encoded once, time = {:.3f}".format(scan, "/" + light if light else "", len(views),
+                                                                     time.time() - start))
+            # pass 2: the samples, from cameras only
+            dataset.load_images = False
+            loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=min(args.num_workers, 2), drop_last=False)
+            for sample in loader:
+                start = time.time()
+                ids = [int(v) for v in sample["view_ids"][0]]
+                ref_img = images[ids[0]]
+                depth, confidence, _ = model([ref_img] * len(ids), sample["intrinsics"].to(device),
+                                             sample["extrinsics"].to(device), sample["depth_min"].to(device),
+                                             sample["depth_max"].to(device), features=[pyramids[v] for v in ids])
+                _write_maps(args, sample, depth, confidence, produced)
+                done += 1
+                print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
+            dataset.load_images = True
     return produced
 
 
@@ -179,8 +217,8 @@ def build_parser():
     # additions
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader worker processes per rank")
     p.add_argument("--feature_cache", type=int, default=64,
-                   help="views whose FeatureNet pyramids stay cached on the device per rank (0 = re-encode every sample "
-                        "like the reference; needs --batch_size 1)")
+                   help="> 0: decode and encode every view of a scan ONCE per rank and keep its FeatureNet pyramid on the device "
+                        "(0 = re-decode and re-encode per sample like the reference; needs --batch_size 1)")
     return p
 
 

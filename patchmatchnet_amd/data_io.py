@@ -47,6 +47,17 @@ def scale_to_max_dim(image: np.ndarray, max_dim: int) -> Tuple[np.ndarray, int, 
     return image, h0, w0
 
 
+def image_shape(filename: str, max_dim: int = -1) -> Tuple[int, int, int, int]:
+    """(height, width) read_image would return for this file and max_dim, plus the original (height, width) -- from the
+    image header only (no decode)."""
+    with Image.open(filename) as im:
+        w0, h0 = im.size
+    scale = max_dim / max(h0, w0)
+    if 0 < scale < 1:
+        return int(scale * h0), int(scale * w0), h0, w0
+    return h0, w0, h0, w0
+
+
 def read_image(filename: str, max_dim: int = -1) -> Tuple[np.ndarray, int, int]:
     """RGB image as float32 in [0,1], optionally down-scaled (reference data_io.py:34-47)."""
     arr = np.array(Image.open(filename), dtype=np.float32) / 255.0

@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 from torch.utils.data import Dataset
 
-from .data_io import read_cam_file, read_image, read_pair_file
+from .data_io import image_shape, read_cam_file, read_image, read_pair_file
 
 
 class MVSDataset(Dataset):
@@ -23,6 +23,7 @@ class MVSDataset(Dataset):
         super().__init__()
         self.data_path, self.num_views, self.max_dim = data_path, num_views, max_dim
         self.cam_folder, self.image_folder, self.image_extension = cam_folder, image_folder, image_extension
+        self.load_images = True  # False: samples carry cameras and image SHAPES only (eval.py's encode-once path)
         if os.path.isfile(scan_list):
             with open(scan_list) as f:
                 scans = [ln.rstrip() for ln in f.readlines()]
@@ -45,19 +46,43 @@ class MVSDataset(Dataset):
     def __len__(self) -> int:
         return len(self.metas)
 
+    def image_path(self, scan: str, light: str, vid: int) -> str:
+        return os.path.join(self.data_path, scan, self.image_folder, light, "{:0>8}{}".format(vid, self.image_extension))
+
+    def groups(self) -> "Dict[Tuple[str, str], List[int]]":
+        """Sample indices of this (sharded) dataset per (scan, light), in order."""
+        out: Dict[Tuple[str, str], List[int]] = {}
+        for i, (scan, light, _, _) in enumerate(self.metas):
+            out.setdefault((scan, light), []).append(i)
+        return out
+
+    def views_of(self, indices: List[int]) -> List[int]:
+        """Every view id the given samples read (reference + the source views actually used), sorted."""
+        ids = set()
+        for i in indices:
+            _, _, ref, src = self.metas[i]
+            ids.update([ref] + src[:min(len(src), self.num_views)])
+        return sorted(ids)
+
+
     def __getitem__(self, idx: int) -> Dict:
         scan, light, ref_view, src_views = self.metas[idx]
         view_ids = [ref_view] + src_views[:min(len(src_views), self.num_views)]
         images, intrinsics, extrinsics = [], [], []
         depth_min = depth_max = -1.0
         for i, vid in enumerate(view_ids):
-            img, h0, w0 = read_image(os.path.join(self.data_path, scan, self.image_folder, light,
-                                                  "{:0>8}{}".format(vid, self.image_extension)), self.max_dim)
-            images.append(np.ascontiguousarray(img.transpose(2, 0, 1)))
+            path = self.image_path(scan, light, vid)
+            if self.load_images:
+                img, h0, w0 = read_image(path, self.max_dim)
+                images.append(np.ascontiguousarray(img.transpose(2, 0, 1)))
+                hi, wi = img.shape[0], img.shape[1]
+            else:
+                hi, wi, h0, w0 = image_shape(path, self.max_dim)
+                images.append(np.asarray([hi, wi], np.int64))
             K, E, depth_params = read_cam_file(os.path.join(self.data_path, scan, self.cam_folder,
                                                             "{:0>8}_cam.txt".format(vid)))
-            K[0] *= img.shape[1] / w0
-            K[1] *= img.shape[0] / h0
+            K[0] *= wi / w0
+            K[1] *= hi / h0
             intrinsics.append(K)
             extrinsics.append(E)
             if i == 0:
@@ -66,3 +91,20 @@ class MVSDataset(Dataset):
                 "depth_min": depth_min, "depth_max": depth_max, "ref_view": view_ids[0],
                 "view_ids": np.asarray(view_ids, np.int64), "scan": scan, "light": light,
                 "filename": os.path.join(scan, "{}", "{:0>8}".format(view_ids[0]) + "{}")}
+
+
+class MVSViewDataset(Dataset):
+    """The distinct images of one (scan, light) -- each decoded ONCE (eval.py's encode-once path; the reference decodes and
+    encodes an image once per sample it appears in)."""
+
+    def __init__(self, parent: MVSDataset, scan: str, light: str, view_ids: List[int]) -> None:
+        super().__init__()
+        self.parent, self.scan, self.light, self.view_ids = parent, scan, light, list(view_ids)
+
+    def __len__(self) -> int:
+        return len(self.view_ids)
+
+    def __getitem__(self, idx: int) -> Dict:
+        vid = self.view_ids[idx]
+        img, _, _ = read_image(self.parent.image_path(self.scan, self.light, vid), self.parent.max_dim)
+        return {"image": np.ascontiguousarray(img.transpose(2, 0, 1)), "view": vid}

@@ -88,6 +88,30 @@ def test_scan_reader_and_sharding(tmp_path):
     assert pdist.shard_views([0, 1, 2, 3, 4], 1, 3) == [1, 4]
 
 
+def test_camera_only_samples_and_view_dataset(tmp_path):
+    """eval.py's encode-once path: samples without pixels carry the same cameras (intrinsics scaled from the image header
+    alone) and the view dataset yields every distinct image of a group once."""
+    from patchmatchnet_amd.mvs import MVSViewDataset
+    synth.write_scan(str(tmp_path), "scan1", n_views=5, H=64, W=96, n_src=3)
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("scan1\n")
+    ds = MVSDataset(str(tmp_path), num_views=2, max_dim=48, scan_list=str(tmp_path / "list.txt"))
+    full = ds[1]
+    ds.load_images = False
+    lean = ds[1]
+    np.testing.assert_array_equal(full["intrinsics"], lean["intrinsics"])
+    np.testing.assert_array_equal(full["extrinsics"], lean["extrinsics"])
+    assert [tuple(x) for x in lean["images"]] == [im.shape[1:] for im in full["images"]]
+    groups = ds.groups()
+    assert list(groups) == [("scan1", "")] and groups[("scan1", "")] == list(range(5))
+    views = ds.views_of(groups[("scan1", "")])
+    assert views == sorted(set(views)) and set(views) <= set(range(5))
+    vds = MVSViewDataset(ds, "scan1", "", views)
+    assert len(vds) == len(views)
+    item = vds[0]
+    assert item["view"] == views[0] and item["image"].shape == full["images"][0].shape
+
+
 def _gather_worker(rank, world, port, H, W, ids, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
