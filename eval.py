@@ -123,7 +123,7 @@ def save_depth(args, rank, world, device):
                                                                      time.time() - start))
             # pass 2: the samples, from cameras only
             dataset.load_images = False
-            loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=min(args.num_workers, 2), drop_last=False)
+            loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=0, drop_last=False)  # camera text files only
             for sample in loader:
                 start = time.time()
                 ids = [int(v) for v in sample["view_ids"][0]]
