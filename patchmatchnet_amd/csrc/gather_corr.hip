@@ -471,14 +471,37 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         if (MODE != MODE_NEIGHBOR) pose = make_pose(a.proj + ((size_t)b * N + v) * 16);
         const float4* srcv = reinterpret_cast<const float4*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
                              ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * LPI + lc;
+        const char* sbase = reinterpret_cast<const char*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
+                            ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * (C * 4);
+        const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
         for (int dc0 = 0; dc0 < D; dc0 += DCH) {
             const int dc1 = min(D, dc0 + DCH);
             phase_a(pose, dc0, dc1, 0);
             __syncthreads();
             const float4* rw = recw + grp;
             const int* ro = reco + grp;
-#pragma unroll 4
-            for (int d = dc0; d < dc1; ++d) {
+            // batches of NBP items: records from LDS + all corner loads first, then the blends (hipcc does not unroll this
+            // run-time-bounded loop by itself: one item = 4 loads in flight per wave, a latency chain per hypothesis)
+            constexpr int NBP = 2;
+            int d = dc0;
+            for (; d + NBP <= dc1; d += NBP) {
+                PmnCorners cn[NBP];
+                float4 wq[NBP];
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) {
+                    const int r = (d + i - dc0) * NPIX;
+                    wq[i] = rw[r];
+                    cn[i] = load_corners<C>(sbase, (unsigned)ro[r] * (C * 4) + lane_bytes, row_bytes);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) {
+                    const float s = blend_corners<LPG, CG>(cn[i], wq[i], refq);
+                    if (owner) simt[gB * SS + (d + i) * NPIX + grp] = s;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; d < dc1; ++d) {
                 const float s = gather_item<LPI, LPG, CG>(srcv, rw[(d - dc0) * NPIX], ro[(d - dc0) * NPIX], ws, refq);
                 if (owner) simt[gB * SS + d * NPIX + grp] = s;
             }
