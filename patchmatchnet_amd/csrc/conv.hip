@@ -330,9 +330,11 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
                                                          const float* __restrict__ s0, const float* __restrict__ w1,
                                                          const float* __restrict__ s1, float* __restrict__ out, int N,
                                                          int H, int W) {
-    constexpr int TW = 16, TH = 16, IW = 20, IWP = 21, MW = 18, MP = 12;  // input patch 20x20 (pitch 21), mid 18x18 (12 words/px)
+    // input patch 20x20 (pitch 21); mid 18x18 pixels x 12 words with a 256-word ROW pitch: 12/4 is odd and the row pitch is a
+    // multiple of 64 banks, so the ds_read_b128 of conv1 (16 lanes = 8 + 8 pixels of two tile rows) touches every bank once
+    constexpr int TW = 16, TH = 16, IW = 20, IWP = 21, MW = 18, MP = 12, MRP = 256;
     __shared__ float xin[3 * IW * IWP];
-    __shared__ float4 mid4[MW * MW * MP / 4];
+    __shared__ float4 mid4[MW * MRP / 4];
     float* mid = reinterpret_cast<float*>(mid4);
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
         const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = inside ? fmaxf(acc[c] + cs0[c], 0.0f) : 0.0f;
-        *reinterpret_cast<float4*>(mid + m * MP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(mid + m * MP + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        *reinterpret_cast<float4*>(mid + r * MRP + q * MP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(mid + r * MRP + q * MP + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
     float o[8];
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void stem_kernel(const float* __restrict
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll 1
         for (int kx = 0; kx < 3; ++kx) {
-            const float* mp = mid + ((ty + ky) * MW + tx + kx) * MP;
+            const float* mp = mid + (ty + ky) * MRP + (tx + kx) * MP;
             const float4 a = *reinterpret_cast<const float4*>(mp), b = *reinterpret_cast<const float4*>(mp + 4);
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             const cfloat* wq = cw1 + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * 64);

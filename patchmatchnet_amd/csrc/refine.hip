@@ -133,10 +133,13 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __r
                                                                 const float* __restrict__ dnorm,
                                                                 const float* __restrict__ dmin, const float* __restrict__ dmax,
                                                                 float* __restrict__ out, int B, int H, int W) {
-    constexpr int TW = 16, TH = 16, IW = 20, XP = 20, MW = 18, MP = 12;  // x16 patch 20x20 px x 20 words, conv3 map 18x18 px x 12 words
+    // x16 patch 20x20 px x 20 words, row pitch 424 words; conv3 map 18x18 px x 12 words, row pitch 256 words: with these row
+    // pitches the ds_read_b128 of both phases are bank-conflict free (brute-forced over the 16-lane service groups of a wave64
+    // b128 read; the dense pitches 400 / 216 cost 1.8x / 2x the LDS cycles)
+    constexpr int TW = 16, TH = 16, IW = 20, XP = 20, XRP = 424, MW = 18, MP = 12, MRP = 256;
     extern __shared__ float4 rt_lds4[];
     float* xs = reinterpret_cast<float*>(rt_lds4);
-    float* mid = xs + IW * IW * XP;
+    float* mid = xs + IW * XRP;
     const cfloat* cw3 = (const cfloat*)w3;  // [2 halves][3][3][16][4]
     const cfloat* cs3 = (const cfloat*)s3;
     const cfloat* cwr = (const cfloat*)wr;  // [3][3][8]
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int idx = tid + k * PMN_BLOCK, pix = idx >> 2, q = idx & 3;
-            if (idx < TOT) *reinterpret_cast<float4*>(xs + pix * XP + 4 * q) = v[k];
+            if (idx < TOT) *reinterpret_cast<float4*>(xs + (pix / IW) * XRP + (pix % IW) * XP + 4 * q) = v[k];
         }
     }
     __syncthreads();
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __r
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll 1
             for (int kx = 0; kx < 3; ++kx) {  // rolled: one tap's 64 weights in SGPRs at a time (unrolled, hipcc hoists all 576 and spills)
-                const float* ip = xs + ((r + ky) * IW + q + kx) * XP;
+                const float* ip = xs + (r + ky) * XRP + (q + kx) * XP;
                 const cfloat* wq = wh + __builtin_amdgcn_readfirstlane((ky * 3 + kx) * 64);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __r
         o.y = inside ? fmaxf(acc[1] + sh[1], 0.0f) : 0.0f;
         o.z = inside ? fmaxf(acc[2] + sh[2], 0.0f) : 0.0f;
         o.w = inside ? fmaxf(acc[3] + sh[3], 0.0f) : 0.0f;
-        if (m < MW * MW) *reinterpret_cast<float4*>(mid + m * MP + half * 4) = o;
+        if (m < MW * MW) *reinterpret_cast<float4*>(mid + r * MRP + q * MP + half * 4) = o;
     }
     __syncthreads();
 
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void refine_tail_kernel(const float* __r
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const float* mp = mid + ((ty + ky) * MW + tx + kx) * MP;
+            const float* mp = mid + (ty + ky) * MRP + (tx + kx) * MP;
             const float4 a = *reinterpret_cast<const float4*>(mp), b = *reinterpret_cast<const float4*>(mp + 4);
             const cfloat* wq = cwr + (ky * 3 + kx) * 8;
             res = fmaf(a.x, wq[0], res); res = fmaf(a.y, wq[1], res); res = fmaf(a.z, wq[2], res); res = fmaf(a.w, wq[3], res);
@@ -229,7 +232,10 @@ extern "C" int pmn_refine_tail(const float* x16, const float* w3, const float* s
                                const float* depth_min, const float* depth_max, float* out, int B, int H, int W, void* stream) {
     if (!x16 || !w3 || !s3 || !wr || !dnorm || !depth_min || !depth_max || !out || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
         return PMN_ERR_ARG;
-    const size_t lds = (size_t)(20 * 20 * 20 + 18 * 18 * 12) * sizeof(float);  // 47.6 KB
+    const size_t lds = (size_t)(20 * 424 + 18 * 256) * sizeof(float);  // 52.4 KB
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(refine_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return PMN_ERR_LAUNCH;
     const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
     hipLaunchKernelGGL(refine_tail_kernel, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, x16, w3, s3, wr, dnorm,
                        depth_min, depth_max, out, B, H, W);
