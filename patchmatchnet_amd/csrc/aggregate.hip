@@ -143,6 +143,12 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     a.depth_out[(size_t)b * hw + p] = out;
 }
 
+__device__ __forceinline__ float sigmoid_rcp(float x) {  // 1 / (1 + exp(-x)) for |x| <= 4, relative error < 4e-7
+    const float d = 1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    float r = __builtin_amdgcn_rcpf(d);
+    return r * fmaf(-d, r, 2.0f);
+}
+
 // ---- main kernel: D % 4 == 0, thread = (pixel, hypothesis quad) ------------------------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regress_q4_kernel(const AggArgs a) {
@@ -178,6 +184,13 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
         }
     }
 
+    // Per (pixel, hypothesis, neighbour) the reference does three divisions and an exp (models/patchmatch.py:663-668, :509) --
+    // 50 of the ~60 VALU instructions of this kernel's inner step, which is VALU-bound (68 % busy).  Here: multiply by
+    // 1/interval_scale, sigmoid through v_exp_f32 + v_rcp_f32 with one Newton step (relative error < 4e-7 on [-4,4]), one IEEE
+    // reciprocal of the weight sum per hypothesis instead of K divisions.  Measured 418 -> 336 us over the five launches of a
+    // depth map; probabilities / depth stay inside the parity tolerances (2e-4 abs / 2e-5 rel, tests/test_hip_parity.py).
+    // The scalar fallback kernel keeps the reference's operation sequence.
+    const float inv_interval = 1.0f / a.interval_scale;
     const float* xn = a.xnorm + (size_t)b * hw * D + 4 * q;
     const float* cs = a.cost + (size_t)b * hw * D + 4 * q;
     const float4 xc4 = *reinterpret_cast<const float4*>(xn + (size_t)p * D);
@@ -201,19 +214,21 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
             for (int j = 0; j < 4; ++j) {
                 const float x1 = fmaf(x11[j], w11[k], fmaf(x10[j], w10[k], fmaf(x01[j], w01[k], x00[j] * w00[k])));
                 ck[k][j] = fmaf(c11[j], w11[k], fmaf(c10[j], w10[k], fmaf(c01[j], w01[k], c00[j] * w00[k])));
-                float t = fabsf(x1 - xc[j]) / a.interval_scale;
+                float t = fabsf(x1 - xc[j]) * inv_interval;
                 t = fminf(fmaxf(t, 0.0f), 4.0f);
-                wk[k][j] = pmn_sigmoid(4.0f - 2.0f * t) * fw[k];
+                wk[k][j] = sigmoid_rcp(4.0f - 2.0f * t) * fw[k];
                 wsum[j] = wsum[j] + wk[k][j];
             }
         }
     }
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, rsum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rsum[j] = 1.0f / wsum[j];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < K) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] = s[j] + ck[k][j] * (wk[k][j] / wsum[j]);
+            for (int j = 0; j < 4; ++j) s[j] = s[j] + ck[k][j] * (wk[k][j] * rsum[j]);
         }
 
     // exp(log_softmax) over the D hypotheses of the pixel: max, log-sum-exp, probabilities; then the regression
