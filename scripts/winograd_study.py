@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Numerics study for a Winograd F(2x2,3x3) version of FeatureNet's 3x3 stride-1 layers (candidate for the next round: 2.25x
+fewer matrix-core MACs on conv3,4,6,7,9,10 = 80 of the 156 GFLOP of a six-view FeatureNet).  Runs on CPU: fp32 Winograd with
+fp64-transformed filters vs fp32 direct convolution, both against fp64, on the checkpoint's own layers and realistic
+activations (the golden case's images pushed through the preceding layers)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, torch.nn.functional as F
+import goldenutil as GU
+from patchmatchnet_amd.net import FeatureNet
+
+G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+
+def winograd_conv(x, w, dtype):
+    """x [N,C,H,W] (H, W even), w [K,C,3,3]; padding 1; arithmetic in `dtype` (filters transformed in fp64 first)."""
+    N, C, H, W = x.shape
+    U = (G @ w.double() @ G.t()).to(dtype)                      # [K,C,4,4]
+    xp = F.pad(x.to(dtype), (1, 1, 1, 1))
+    tiles = xp.unfold(2, 4, 2).unfold(3, 4, 2)                   # [N,C,H/2,W/2,4,4]
+    V = Bt.to(dtype) @ tiles @ Bt.t().to(dtype)                  # input transform
+    M = torch.einsum("kcab,nchwab->nkhwab", U, V)               # 16 GEMMs
+    Y = At.to(dtype) @ M @ At.t().to(dtype)                      # [N,K,H/2,W/2,2,2]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, -1, H, W)
+
+g, params, kw = GU.load_case("default")
+net = FeatureNet()
+net.load_state_dict({k[len("feature."):]: torch.from_numpy(v) for k, v in params.items() if k.startswith("feature.")})
+net.eval()
+x = torch.cat([torch.from_numpy(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
+acts = {}
+with torch.no_grad():
+    t = x
+    for i in range(11):
+        acts[i] = t
+        t = getattr(net, f"conv{i}")(t)
+    for i in (3, 4, 6, 7, 9, 10):
+        m = getattr(net, f"conv{i}")
+        s = m.bn.weight.double() / torch.sqrt(m.bn.running_var.double() + m.bn.eps)
+        w = m.conv.weight.double() * s[:, None, None, None]
+        xin = acts[i]
+        ref = F.conv2d(xin.double(), w, None, 1, 1)
+        d32 = F.conv2d(xin, w.float(), None, 1, 1).double()
+        w32 = winograd_conv(xin, w, torch.float32).double()
+        scale = ref.abs().max()
+        print(f"conv{i}: {tuple(xin.shape)} -> direct fp32 max err {float((d32 - ref).abs().max() / scale):.2e}   "
+              f"winograd fp32 max err {float((w32 - ref).abs().max() / scale):.2e}   rms {float(((w32 - ref) ** 2).mean().sqrt() / scale):.2e}")
