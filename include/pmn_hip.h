@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 8
+#define PMN_ABI_VERSION 9
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -143,6 +143,14 @@ int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float
  *                cout <= 64 (other dilations: pmn_conv2d). */
 int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, float *out, float *out_b, int N, int H, int W,
                     int cin, int cout, int ca, int K, int stride, int pad, int dil, int relu, int planar, void *stream);
+
+/* Winograd F(2x2,3x3) form of FeatureNet's 3x3 stride-1 ConvBnReLU layers with cin == cout == C in {16, 32, 64} (conv3/4, conv6/7,
+ * conv9/10; reference models/net.py:21-31) on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): 16 instead of 36 multiplies per 2x2
+ * output tile and input channel, same fp32 error level as the direct form (scripts/winograd_study.py).  in / out [N,H,W,C]
+ * channels-last; weights DEVICE float [C/16][16][C/16][64][4] = G g G^T with the BatchNorm scale folded in, computed in float64 and
+ * laid out in matrix-operand lane order (patchmatchnet_amd/params.py: pack_conv_wino); shift DEVICE float[C]. */
+int pmn_conv3x3_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int C, int relu,
+                     void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

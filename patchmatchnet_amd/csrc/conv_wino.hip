@@ -1,0 +1,201 @@
+// conv_wino.hip -- Winograd F(2x2,3x3) fp32 convolution on the matrix cores for FeatureNet's 3x3 stride-1 layers with
+// cin == cout == C in {16, 32, 64} (reference models/net.py:21-23, 26-27, 30-31: conv3/4, conv6/7, conv9/10), conv + folded
+// BatchNorm shift + ReLU, channels-last in and out.
+//
+// Why: these six layers are 80 of the 156 GFLOP of a six-view FeatureNet, and every convolution kernel of this library is
+// bound by its multiply rate (VALU 81-83 % busy, matrix pipe ~60 % busy).  F(2x2,3x3) spends 16 multiplies per 2x2 output
+// tile and input channel instead of 36: Y = A^T [ (G g G^T) . (B^T d B) ] A.  The filter transform U = G g G^T is done on the
+// host in float64 (params.pack_conv_wino); in fp32 the result carries the same 2-3e-7 relative error as a direct fp32
+// convolution on this network's own layers and activations (scripts/winograd_study.py).
+//
+// Mapping.  A workgroup owns 32 tiles = 8 x 16 output pixels (4 x 8 tiles) and all C output channels.  Per chunk of 16 input
+// channels: (1) the 10 x 18 input patch goes to LDS (zero-filled outside the image); (2) thread (tile, channel quad) forms the
+// 16 transformed values B^T d B of its tile -- adds only -- and writes V[pos][tile][16] to LDS; (3) for each of the 16
+// transform positions the waves run  M_pos[16 tiles x 16 couts] += V_pos[16 tiles x 16 cin] . U_pos[16 cin x 16 couts]
+// as four v_mfma_f32_16x16x4_f32 (exact fp32).  A wave owns one block of 16 output channels and one or two groups of 16
+// tiles, so the inverse transform never crosses lanes: it is linear, and every finished M_pos is folded straight into the
+// wave's four output accumulators Y[a][b] with its +-1/0 coefficient A^T[a][p] A^T[b][q] (no 16-position accumulator file).
+//   A operand  lane (i = lane&15, kq = lane>>4): ONE ds_read_b128 = channels [4 kq, +4) of tile i at the position; element m
+//              feeds MFMA m (k index kq <-> input channel 4 kq + m)
+//   B operand  U repacked on the host to [chunk][pos][cout block][64 lanes][4]: one contiguous 1 KB load per wave, positions
+//              run 4 deep ahead in a register ring
+//   C/D        16x16 MFMA: lane holds column (lane&15) = output channel, rows 4*(lane>>4) + r = tiles
+#include "pmn_common.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoArgs {
+    int N, H, W, relu;
+};
+
+__device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int C>
+__global__ __launch_bounds__((C == 16 ? 128 : 256), 3) void conv_wino_kernel(const float* __restrict__ in,
+                                                                             const float4* __restrict__ wU,
+                                                                             const float* __restrict__ shift,
+                                                                             float* __restrict__ out, const WinoArgs a) {
+    constexpr int NCB = C / 16, NW = (C == 16 ? 2 : 4), TG = (C == 64 ? 2 : 1), NTHR = 64 * NW;
+    constexpr int CCP = 20, PH = 10, PW = 18, VP = 16, NT = 32;  // patch pitch 20 words / pixel; V pitch 16 words / tile
+    __shared__ float4 P4[PH * PW * CCP / 4];
+    __shared__ float4 V4[16 * NT * VP / 4];
+    float* P = reinterpret_cast<float*>(P4);
+    float* V = reinterpret_cast<float*>(V4);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int cb = wave % NCB, g0 = (C == 64) ? 0 : wave / NCB;
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * 8, ox0 = (tr % tiles_x) * 16;
+
+    f32x4 Y[TG][2][2];
+#pragma unroll
+    for (int g = 0; g < TG; ++g)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Y[g][p >> 1][p & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float4* bl = wU + (size_t)cb * 64 + lane;
+#pragma unroll 1
+    for (int cc = 0; cc < NCB; ++cc) {
+        float4 bq[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bq[d] = bl[(size_t)((cc * 16 + d) * NCB) * 64];
+        if (cc) __syncthreads();  // the previous chunk's MFMA phase is done with V (and P is long free)
+        {   // (1) patch: PH x PW pixels x 4 channel quads, every load of the thread in flight before the first LDS write
+            constexpr int TOT = PH * PW * 4, NL = (TOT + NTHR - 1) / NTHR;
+            float4 v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int idx = tid + k * NTHR, pix = idx >> 2, q = idx & 3;
+                const int gy = oy0 - 1 + pix / PW, gx = ox0 - 1 + pix % PW;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v[k] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * C + cc * 16 + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int idx = tid + k * NTHR, pix = idx >> 2, q = idx & 3;
+                if (idx < TOT) *reinterpret_cast<float4*>(P + pix * CCP + 4 * q) = v[k];
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 4) {  // (2) input transform B^T d B of (tile, channel quad)
+            const int t = tid >> 2, c4 = tid & 3, ty = t >> 3, tx = t & 7;
+            const float* pp = P + ((2 * ty) * PW + 2 * tx) * CCP + 4 * c4;
+            float4 w[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4 d0 = *reinterpret_cast<const float4*>(pp + (0 * PW + b) * CCP);
+                const float4 d1 = *reinterpret_cast<const float4*>(pp + (1 * PW + b) * CCP);
+                const float4 d2 = *reinterpret_cast<const float4*>(pp + (2 * PW + b) * CCP);
+                const float4 d3 = *reinterpret_cast<const float4*>(pp + (3 * PW + b) * CCP);
+                w[0][b] = f4sub(d0, d2);
+                w[1][b] = f4add(d1, d2);
+                w[2][b] = f4sub(d2, d1);
+                w[3][b] = f4sub(d1, d3);
+            }
+            float* vp = V + t * VP + 4 * c4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<float4*>(vp + ((4 * p + 0) * NT) * VP) = f4sub(w[p][0], w[p][2]);
+                *reinterpret_cast<float4*>(vp + ((4 * p + 1) * NT) * VP) = f4add(w[p][1], w[p][2]);
+                *reinterpret_cast<float4*>(vp + ((4 * p + 2) * NT) * VP) = f4sub(w[p][2], w[p][1]);
+                *reinterpret_cast<float4*>(vp + ((4 * p + 3) * NT) * VP) = f4sub(w[p][1], w[p][3]);
+            }
+        }
+        __syncthreads();
+        // (3) 16 positions: M_pos = V_pos . U_pos over this chunk's 16 input channels, folded into Y with the inverse-transform
+        // coefficient of the position.  Two positions at a time (independent MFMA chains: the 16x16x4 result latency is 40 cycles
+        // against a 32-cycle issue); sched_barriers keep the B ring reloads behind the MFMAs that read the slot.
+        const float* va = V + (g0 * 16 + j) * VP + 4 * kq;
+#pragma unroll
+        for (int pos = 0; pos < 16; pos += 2) {
+            f32x4 M[2][TG];
+            float4 av[2][TG];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < TG; ++g) {
+                    M[u][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    av[u][g] = *reinterpret_cast<const float4*>(va + ((pos + u) * NT + g * 16) * VP);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 b4 = bq[(pos + u) & 3];
+                    const float bf = m == 0 ? b4.x : m == 1 ? b4.y : m == 2 ? b4.z : b4.w;
+#pragma unroll
+                    for (int g = 0; g < TG; ++g) {
+                        const float4 a4 = av[u][g];
+                        const float af = m == 0 ? a4.x : m == 1 ? a4.y : m == 2 ? a4.z : a4.w;
+                        M[u][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, M[u][g], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (pos + u + 4 < 16) bq[(pos + u) & 3] = bl[(size_t)((cc * 16 + pos + u + 4) * NCB) * 64];
+                // inverse transform A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]: coefficient of position (p,q) in output (a,b)
+                const int p = (pos + u) >> 2, q = (pos + u) & 3;
+#pragma unroll
+                for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob) {
+                        const int ca = oa == 0 ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : p == 1 ? 1 : -1);
+                        const int cbq = ob == 0 ? (q < 3 ? 1 : 0) : (q == 0 ? 0 : q == 1 ? 1 : -1);
+                        const int cf = ca * cbq;
+#pragma unroll
+                        for (int g = 0; g < TG; ++g) {
+                            if (cf == 1) Y[g][oa][ob] += M[u][g];
+                            if (cf == -1) Y[g][oa][ob] -= M[u][g];
+                        }
+                    }
+            }
+        }
+    }
+
+    // epilogue: + shift (folded BatchNorm), ReLU, channels-last store: lane = output channel 16 cb + j, rows r = tiles 4 kq + r
+    const float sh = shift[cb * 16 + j];
+#pragma unroll
+    for (int g = 0; g < TG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = (g0 + g) * 16 + kq * 4 + r, ty = t >> 3, tx = t & 7;
+#pragma unroll
+            for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const int oy = oy0 + 2 * ty + oa, ox = ox0 + 2 * tx + ob;
+                    float v = Y[g][oa][ob][r] + sh;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    if (oy < a.H && ox < a.W) out[(((size_t)n * a.H + oy) * a.W + ox) * C + cb * 16 + j] = v;
+                }
+        }
+}
+
+template <int C>
+static int launch_wino(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
+    const int blocks = a.N * ((a.W + 15) / 16) * ((a.H + 7) / 8);
+    hipLaunchKernelGGL(conv_wino_kernel<C>, dim3(blocks), dim3(C == 16 ? 128 : 256), 0, st, in,
+                       reinterpret_cast<const float4*>(w), shift, out, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// in [N,H,W,C] channels-last; weights DEVICE float [C/16][16][C/16][64][4] (params.pack_conv_wino: U = G g G^T with the
+// BatchNorm scale folded in, in float64, laid out in B-operand lane order); shift DEVICE float[C]; out [N,H,W,C].
+// 3x3, stride 1, padding 1, cin == cout == C in {16, 32, 64}.
+extern "C" int pmn_conv3x3_wino(const float* in, const float* weights, const float* shift, float* out, int N, int H, int W, int C,
+                                int relu, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    WinoArgs a;
+    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) return launch_wino<64>(in, weights, shift, out, a, st);
+    if (C == 32) return launch_wino<32>(in, weights, shift, out, a, st);
+    if (C == 16) return launch_wino<16>(in, weights, shift, out, a, st);
+    return PMN_ERR_SHAPE;
+}

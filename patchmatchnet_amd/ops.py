@@ -390,6 +390,21 @@ def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: 
     return out
 
 
+def conv3x3_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """pmn_conv3x3_wino: 3x3 / stride 1 / padding 1 convolution with cin == cout in {16,32,64} + folded-BN shift + ReLU in
+    Winograd F(2x2,3x3) form on the matrix cores; x [N,H,W,C] channels-last, weights from params.pack_conv_wino."""
+    for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
+        _dev(t_, n_)
+    N, H, W, C = x.shape
+    if tuple(weights.shape) != (C // 16, 16, C // 16, 64, 4) or tuple(shift.shape) != (C,):
+        raise PmnError("conv3x3_wino: weights are not in pack_conv_wino layout for this input")
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv3x3_wino(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, H, W, C,
+                                          1 if relu else 0, _stream(x)), "pmn_conv3x3_wino")
+    return out
+
+
 def pointwise_split_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int):
     """pmn_conv2d_mfma, 1x1 form: out = x @ W + shift on the matrix cores with the output channels split between two
     channels-last tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights from

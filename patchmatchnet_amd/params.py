@@ -158,6 +158,33 @@ def pack_refine_tail(conv3_weight, conv3_bn, res_weight, eps: float = BN_EPS):
     return w3, s, wr
 
 
+_WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def pack_conv_wino(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
+    """3x3 Conv2d weight [C,C,3,3] with C in {16,32,64} (+ BatchNorm2d tensors or a conv bias) -> (float32 [C/16, 16, C/16, 64, 4],
+    float32 [C]) for pmn_conv3x3_wino: the Winograd F(2x2,3x3) filter transform U = G g G^T (float64, BatchNorm scale folded
+    in first), laid out so that lane (j = lane&15, kq = lane>>4) of output-channel block cb reads, for input-channel chunk cc
+    and transform position pos = 4p+q, the four values U[p][q][cin = 16cc + 4kq + m][cout = 16cb + j], m = 0..3."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if K != 3 or cin != cout or cin not in (16, 32, 64):
+        raise ValueError("pack_conv_wino: 3x3 with cin == cout in {16, 32, 64}")
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        s = g / np.sqrt(v + eps)
+        w = w * s[:, None, None, None]
+        shift = b - m * s
+    elif bias is not None:
+        shift = _np64(bias)
+    else:
+        shift = np.zeros(cout)
+    U = np.einsum("pa,kcab,qb->pqck", _WINO_G, w, _WINO_G).reshape(16, cin, cout)  # [pos][cin][cout]
+    # cin = 16cc + 4kq + m, cout = 16cb + j  ->  [cc][pos][cb][kq*16 + j][m]
+    t = U.reshape(16, cin // 16, 4, 4, cout // 16, 16).transpose(1, 0, 4, 2, 5, 3).reshape(cin // 16, 16, cout // 16, 64, 4)
+    return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

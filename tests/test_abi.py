@@ -184,3 +184,24 @@ def test_pack_conv_mfma_layout():
     assert p3.shape == (25, 4, 2, 64, 4) and s3.shape == (64,)
     np.testing.assert_array_equal(p3[:, :, 0], p[:, :, 0])
     assert not p3[:, :, 1, 18:32].any() and not p3[:, :, 1, 32 + 18:].any() and not s3[50:].any() and s3[49] == 49
+
+
+def test_pack_conv_wino_layout_and_transform():
+    """params.pack_conv_wino: U = G g G^T per (cout, cin), lane (j, kq) of cout block cb holds U[pos][16cc+4kq+m][16cb+j]; the
+    transform reproduces a 3x3 convolution through the Winograd identity on one tile."""
+    from patchmatchnet_amd import params as PR
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((32, 32, 3, 3))
+    p, s = PR.pack_conv_wino(torch.from_numpy(w))
+    assert p.shape == (2, 16, 2, 64, 4) and s.shape == (32,) and not s.any()
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
+    for (cc, pos, cb, j, kq, m) in [(0, 0, 0, 0, 0, 0), (1, 7, 1, 9, 3, 2), (0, 15, 1, 15, 1, 3), (1, 10, 0, 4, 2, 1)]:
+        k, c = 16 * cb + j, 16 * cc + 4 * kq + m
+        U = G @ w[k, c] @ G.T
+        assert abs(p[cc, pos, cb, kq * 16 + j, m] - U[pos // 4, pos % 4]) < 1e-6
+    d = rng.standard_normal((4, 4))
+    y = At @ ((G @ w[5, 7] @ G.T) * (Bt @ d @ Bt.T)) @ At.T
+    ref = np.array([[(d[a:a + 3, b:b + 3] * w[5, 7]).sum() for b in range(2)] for a in range(2)])
+    np.testing.assert_allclose(y, ref, rtol=1e-12, atol=1e-12)

@@ -308,6 +308,32 @@ def test_offset_heads_mfma_against_torch(cin, dil, n_p, n_e, H, W, N):
         assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("C", [16, 32, 64])
+@pytest.mark.parametrize("H,W", [(37, 51), (8, 16), (150, 200)])
+def test_conv3x3_winograd_against_torch(C, H, W):
+    """pmn_conv3x3_wino (Winograd F(2x2,3x3) on the matrix cores) vs F.conv2d + BatchNorm + ReLU in float64 and vs the direct
+    kernel pmn_conv2d; odd sizes (partial tiles, borders), batch 2."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(2, C, H, W, generator=gen)
+    wt = 0.2 * torch.randn(C, C, 3, 3, generator=gen)
+    bn = (0.5 + torch.rand(C, generator=gen), 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen),
+          0.5 + torch.rand(C, generator=gen))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, 1, 1)
+    ref = torch.relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                                    False, 0.0, 1e-5))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w, sh = PP.pack_conv_wino(wt, bn=bn)
+    got = P.ops.conv3x3_wino(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), relu=True)
+    assert tuple(got.shape) == (2, H, W, C)
+    err = float((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    w2, s2 = PP.pack_conv(wt, bn=bn)
+    direct = P.ops.conv2d(xin, torch.from_numpy(w2).to(DEV), torch.from_numpy(s2).to(DEV), C, 3, 1, 1, relu=True)
+    assert float((got - direct).abs().max() / ref.abs().max()) < 1e-5
+
+
 def test_fpn_level8_matrix_core_form_matches_valu_form():
     """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
     P = _gpu()
@@ -334,6 +360,7 @@ def test_featurenet_hip_matches_miopen(fold):
     model = _model(P, params, kw)
     model.feature.fold_fpn = fold
     model.feature.mfma_convs = fold
+    model.feature.winograd = fold
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
