@@ -33,4 +33,9 @@ for cin, cout, K, s, H, W in layers:
         wm, sm = torch.from_numpy(wm).to(dev), torch.from_numpy(sm).to(dev)
         t_m = timeit(lambda: ops.conv2d_mfma(x, wm, sm, K, s, K // 2, relu=True))
         line += f" | mfma {t_m:7.1f} us {gf / t_m * 1e3:6.1f} TF/s"
+    if K == 3 and s == 1 and cin == cout and cin in (16, 32, 64):
+        ww, sw = PP.pack_conv_wino(wt)
+        ww, sw = torch.from_numpy(ww).to(dev), torch.from_numpy(sw).to(dev)
+        t_w = timeit(lambda: ops.conv3x3_wino(x, ww, sw, relu=True))
+        line += f" | wino {t_w:7.1f} us {gf / t_w * 1e3:6.1f} TF/s(direct-equivalent)"
     print(line, flush=True)
