@@ -176,6 +176,116 @@ __global__ __launch_bounds__((C == 16 ? 128 : 256), 3) void conv_wino_kernel(con
         }
 }
 
+// ---- C = 16 (conv3 / conv4 at half resolution): register-resident input transform ------------------------------------------
+// With a single block of 16 output channels nothing shares the transformed tile between waves, so the V buffer of the general
+// kernel (32 KB of LDS per 32 tiles: 6 waves per CU, transforms and barriers dominating the few MFMAs) is dropped: lane (tile i,
+// channel quad kq) reads the 16 patch values of ITS operand (16 ds_read_b128), transforms them in registers and feeds the 64
+// MFMAs of its wave directly.  Workgroup = 4 waves x 16 tiles (16 x 16 pixels), LDS = the 18 x 18 patch only (26 KB).
+__global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __restrict__ in, const float4* __restrict__ wU,
+                                                            const float* __restrict__ shift, float* __restrict__ out,
+                                                            const WinoArgs a) {
+    constexpr int C = 16, CCP = 20, PH = 18, PW = 18, NTHR = 256;
+    __shared__ float4 P4[PH * PW * CCP / 4];
+    float* P = reinterpret_cast<float*>(P4);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * 16, ox0 = (tr % tiles_x) * 16;
+
+    float4 bq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) bq[d] = wU[(size_t)d * 64 + lane];
+    {
+        constexpr int TOT = PH * PW * 4, NL = (TOT + NTHR - 1) / NTHR;
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * NTHR, pix = idx >> 2, q = idx & 3;
+            const int gy = oy0 - 1 + pix / PW, gx = ox0 - 1 + pix % PW;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                v[k] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * C + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * NTHR, pix = idx >> 2, q = idx & 3;
+            if (idx < TOT) *reinterpret_cast<float4*>(P + pix * CCP + 4 * q) = v[k];
+        }
+    }
+    __syncthreads();
+
+    // this lane's A operands: tile t = 16 wave + j (tile row 2 wave + (j >> 3), column j & 7), channels [4 kq, +4), all 16 positions
+    const int ty = 2 * wave + (j >> 3), tx = j & 7;
+    const float* pp = P + ((2 * ty) * PW + 2 * tx) * CCP + 4 * kq;
+    float4 V[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float4 d0 = *reinterpret_cast<const float4*>(pp + (0 * PW + b) * CCP);
+        const float4 d1 = *reinterpret_cast<const float4*>(pp + (1 * PW + b) * CCP);
+        const float4 d2 = *reinterpret_cast<const float4*>(pp + (2 * PW + b) * CCP);
+        const float4 d3 = *reinterpret_cast<const float4*>(pp + (3 * PW + b) * CCP);
+        V[0][b] = f4sub(d0, d2);
+        V[1][b] = f4add(d1, d2);
+        V[2][b] = f4sub(d2, d1);
+        V[3][b] = f4sub(d1, d3);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float4 w0 = V[p][0], w1 = V[p][1], w2 = V[p][2], w3 = V[p][3];
+        V[p][0] = f4sub(w0, w2);
+        V[p][1] = f4add(w1, w2);
+        V[p][2] = f4sub(w2, w1);
+        V[p][3] = f4sub(w1, w3);
+    }
+
+    f32x4 Y[2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Y[p >> 1][p & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pos = 0; pos < 16; pos += 2) {
+        f32x4 M[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4 b4 = bq[(pos + u) & 3], a4 = V[(pos + u) >> 2][(pos + u) & 3];
+                const float bf = m == 0 ? b4.x : m == 1 ? b4.y : m == 2 ? b4.z : b4.w;
+                const float af = m == 0 ? a4.x : m == 1 ? a4.y : m == 2 ? a4.z : a4.w;
+                M[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, M[u], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (pos + u + 4 < 16) bq[(pos + u) & 3] = wU[(size_t)(pos + u + 4) * 64 + lane];
+            const int p = (pos + u) >> 2, q = (pos + u) & 3;
+#pragma unroll
+            for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) {
+                    const int ca = oa == 0 ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : p == 1 ? 1 : -1);
+                    const int cq = ob == 0 ? (q < 3 ? 1 : 0) : (q == 0 ? 0 : q == 1 ? 1 : -1);
+                    if (ca * cq == 1) Y[oa][ob] += M[u];
+                    if (ca * cq == -1) Y[oa][ob] -= M[u];
+                }
+        }
+    }
+    const float sh = shift[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = kq * 4 + r, oty = 2 * wave + (t >> 3), otx = t & 7;  // D rows = tiles 4 kq + r of this wave's 16
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int oy = oy0 + 2 * oty + oa, ox = ox0 + 2 * otx + ob;
+                float v = Y[oa][ob][r] + sh;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (oy < a.H && ox < a.W) out[(((size_t)n * a.H + oy) * a.W + ox) * C + j] = v;
+            }
+    }
+}
+
 template <int C>
 static int launch_wino(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
     const int blocks = a.N * ((a.W + 15) / 16) * ((a.H + 7) / 8);
@@ -196,6 +306,11 @@ extern "C" int pmn_conv3x3_wino(const float* in, const float* weights, const flo
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) return launch_wino<64>(in, weights, shift, out, a, st);
     if (C == 32) return launch_wino<32>(in, weights, shift, out, a, st);
-    if (C == 16) return launch_wino<16>(in, weights, shift, out, a, st);
+    if (C == 16) {
+        const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
+        hipLaunchKernelGGL(conv_wino16_kernel, dim3(blocks), dim3(256), 0, st, in, reinterpret_cast<const float4*>(weights), shift, out, a);
+        PMN_CHECK_LAUNCH();
+        return PMN_OK;
+    }
     return PMN_ERR_SHAPE;
 }

@@ -61,10 +61,8 @@ class FeatureNet(nn.Module):
                     w, s = params.pack_conv_mfma(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                # Winograd for the 32- and 64-channel 3x3 layers (96 / 86 us vs 147 / 158 us direct); at 16 channels the transforms
-                # outweigh the saved multiplies (233 vs 157 us for the VALU kernel) -- pmn_conv3x3_wino supports it, the net skips it
                 if cv.kernel_size[0] == 3 and cv.stride[0] == 1 and cv.in_channels == cv.out_channels and \
-                        cv.in_channels in (32, 64):
+                        cv.in_channels in (16, 32, 64):
                     w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_wino"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
