@@ -8,7 +8,7 @@
 // host in float64 (params.pack_conv_wino); in fp32 the result carries the same 2-3e-7 relative error as a direct fp32
 // convolution on this network's own layers and activations (scripts/winograd_study.py).
 //
-// Mapping.  A workgroup owns 32 tiles = 8 x 16 output pixels (4 x 8 tiles) and all C output channels.  Per chunk of 16 input
+// Mapping (C = 32, 64; the 16-channel kernel further down keeps the transform in registers).  A workgroup owns 32 tiles = 8 x 16 output pixels (4 x 8 tiles) and all C output channels.  Per chunk of 16 input
 // channels: (1) the 10 x 18 input patch goes to LDS (zero-filled outside the image); (2) thread (tile, channel quad) forms the
 // 16 transformed values B^T d B of its tile -- adds only -- and writes V[pos][tile][16] to LDS; (3) for each of the 16
 // transform positions the waves run  M_pos[16 tiles x 16 couts] += V_pos[16 tiles x 16 cin] . U_pos[16 cin x 16 couts]
@@ -32,11 +32,12 @@ __device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return
 __device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 template <int C>
-__global__ __launch_bounds__((C == 16 ? 128 : 256), 3) void conv_wino_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(const float* __restrict__ in,
                                                                              const float4* __restrict__ wU,
                                                                              const float* __restrict__ shift,
                                                                              float* __restrict__ out, const WinoArgs a) {
-    constexpr int NCB = C / 16, NW = (C == 16 ? 2 : 4), TG = (C == 64 ? 2 : 1), NTHR = 64 * NW;
+    static_assert(C == 32 || C == 64, "16 channels: conv_wino16_kernel");
+    constexpr int NCB = C / 16, TG = (C == 64 ? 2 : 1), NTHR = 256;
     constexpr int CCP = 20, PH = 10, PW = 18, VP = 16, NT = 32;  // patch pitch 20 words / pixel; V pitch 16 words / tile
     __shared__ float4 P4[PH * PW * CCP / 4];
     __shared__ float4 V4[16 * NT * VP / 4];
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __rest
 template <int C>
 static int launch_wino(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
     const int blocks = a.N * ((a.W + 15) / 16) * ((a.H + 7) / 8);
-    hipLaunchKernelGGL(conv_wino_kernel<C>, dim3(blocks), dim3(C == 16 ? 128 : 256), 0, st, in,
+    hipLaunchKernelGGL(conv_wino_kernel<C>, dim3(blocks), dim3(256), 0, st, in,
                        reinterpret_cast<const float4*>(w), shift, out, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
