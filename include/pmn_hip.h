@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 9
+#define PMN_ABI_VERSION 10
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -151,6 +151,15 @@ int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, f
  * laid out in matrix-operand lane order (patchmatchnet_amd/params.py: pack_conv_wino); shift DEVICE float[C]. */
 int pmn_conv3x3_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int C, int relu,
                      void *stream);
+
+/* Winograd form of FeatureNet's 5x5 stride-2 ConvBnReLU layers conv2 (8->16), conv5 (16->32), conv8 (32->64) (reference
+ * models/net.py:20, 24, 28): the stride-2 convolution is split into four stride-1 convolutions on the parity sub-images (3x3, 3x2, 2x3,
+ * 2x2 taps), each in minimal-filtering form F(2,3) / F(2,2) per dimension: 49 instead of 100 multiplies per 2x2 output tile and input
+ * channel, on v_mfma_f32_16x16x4_f32.  in [N,H,W,cin] channels-last; weights DEVICE float [cin/8][49][cout/16][64][2]
+ * (patchmatchnet_amd/params.py: pack_conv5x5s2_wino, transforms in float64, BatchNorm scale folded in); shift DEVICE float[cout];
+ * out [N,(H-1)/2+1,(W-1)/2+1,cout].  Supported (cin,cout): (8,16), (16,32), (32,64). */
+int pmn_conv5x5s2_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int cin,
+                       int cout, int relu, void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

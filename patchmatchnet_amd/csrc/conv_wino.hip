@@ -315,3 +315,207 @@ extern "C" int pmn_conv3x3_wino(const float* in, const float* weights, const flo
     }
     return PMN_ERR_SHAPE;
 }
+
+// =================================================================================================================================
+// 5x5 stride-2 ConvBnReLU layers (conv2 8->16, conv5 16->32, conv8 32->64; reference models/net.py:20, 24, 28) in Winograd form.
+//
+// A stride-2 convolution splits into four stride-1 convolutions on the four parity sub-images of the input:
+//   out = sum over (r,s) in {0,1}^2 of  X_rs (*) W_rs,   X_rs[i,j] = in[2i+r, 2j+s],   W_rs[a,b] = w[2a+r, 2b+s]
+// with 3x3, 3x2, 2x3 and 2x2 taps.  Each runs as minimal filtering per dimension -- F(2,3): 4 products, F(2,2): 3 products for 2
+// outputs -- so a 2x2 output tile costs 16 + 12 + 12 + 9 = 49 multiplies per (cin, cout) instead of 100, and all four share the
+// same output tile grid, i.e. the same accumulators.  In fp32 the error is 1-2e-7 relative (below the direct form's 4-5e-7 on this
+// network's layers, scripts/winograd_study.py).
+//
+// Kernel = conv_wino16_kernel's scheme: a wave owns 16 tiles (2 x 8 tiles = 4 x 16 output pixels) x 16 output channels and
+// transforms ITS OWN operands in registers straight from the staged input patch (7 x 7 input pixels per tile, tiles 4 apart),
+// phase by phase (16 / 12 / 12 / 9 values live at a time), 8 input channels per chunk: lane (tile i = lane&15, kq = lane>>4) holds
+// channels 2 kq + {0,1} of its tile (ds_read_b64), element m feeds MFMA m of the position (k index kq <-> channel 2 kq + m).
+// Filter transforms G_r W_rs G_s^T are done on the host in float64 (params.pack_conv5x5s2_wino) and stored [chunk][49 positions]
+// [cout block][64 lanes][2]; positions run 7 deep ahead in a register ring.  The inverse transforms are linear, so every finished
+// position is folded into the four output accumulators with its coefficient (0, +1, -1).
+// =================================================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// coefficient of transformed position p (of a dimension in phase `odd`) in output o (0/1): A^T = [[1,1,1,0],[0,1,-1,-1]] for the
+// 3-tap (even) phase, [[1,1,0],[0,1,-1]] for the 2-tap (odd) phase
+__device__ __forceinline__ constexpr int w5_at(int odd, int o, int p) {
+    return odd ? (o == 0 ? (p < 2 ? 1 : 0) : (p == 0 ? 0 : p == 1 ? 1 : -1))
+               : (o == 0 ? (p < 3 ? 1 : 0) : (p == 0 ? 0 : p == 1 ? 1 : -1));
+}
+
+// in-place input transform of one dimension: even phase (4 points) B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]],
+// odd phase (3 points) [[1,-1,0],[0,1,0],[0,1,-1]]
+template <int ODD>
+__device__ __forceinline__ void w5_bt(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3) {
+    if (ODD) {
+        const f32x2 t0 = d0 - d1, t2 = d1 - d2;
+        d0 = t0; d2 = t2;
+    } else {
+        const f32x2 t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3;
+        d0 = t0; d1 = t1; d2 = t2; d3 = t3;
+    }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __restrict__ in, const f32x2* __restrict__ wU,
+                                                               const float* __restrict__ shift, float* __restrict__ out,
+                                                               const WinoArgs a, const int Ho, const int Wo) {
+    constexpr int NCB = COUT / 16, NG = 4 / NCB, NCH = CIN / 8;      // cout blocks, tile groups per workgroup, chunks of 8 channels
+    constexpr int PH = 8 * NG + 3, PW = 35, PP = 10;                  // patch rows / cols / words per pixel (8 channels + 2 pad)
+    constexpr int NPOS = 49, RING = 7, NTHR = 256;  // 49 % RING == 0: a position keeps its ring slot from chunk to chunk
+    extern __shared__ float4 w5_lds4[];
+    float* P = reinterpret_cast<float*>(w5_lds4);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int cb = wave % NCB, g = wave / NCB;
+    const int tiles_x = (Wo + 15) / 16, tiles_y = (Ho + 4 * NG - 1) / (4 * NG);
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * (4 * NG), ox0 = (tr % tiles_x) * 16;
+    const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
+
+    f32x4 Y[2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Y[p >> 1][p & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x2* bl = wU + (size_t)cb * 64 + lane;  // element ((cc*49 + pos)*NCB + cb)*64 + lane
+    f32x2 bq[RING];
+#pragma unroll
+    for (int d = 0; d < RING; ++d) bq[d] = bl[(size_t)(d * NCB) * 64];
+
+    // this lane's tile inside the group: 2 x 8 tiles, 4 input pixels apart; patch rows of the group start at 8 g
+    const int ty = j >> 3, tx = j & 7;
+    const float* pl = P + ((8 * g + 4 * ty) * PW + 4 * tx) * PP + 2 * kq;
+
+#pragma unroll 1
+    for (int cc = 0; cc < NCH; ++cc) {
+        if (cc) __syncthreads();  // every wave is done with the previous chunk's patch
+        {   // patch: PH x 35 pixels x 2 channel quads; at most SB loads of a thread in flight per batch (register budget)
+            constexpr int TOT = PH * PW * 2, NL = (TOT + NTHR - 1) / NTHR, SB = 5;
+#pragma unroll
+            for (int k0 = 0; k0 < NL; k0 += SB) {
+                float4 v[SB];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int idx = tid + (k0 + k) * NTHR, pix = idx >> 1, q = idx & 1;
+                    const int gy = iy0 + pix / PW, gx = ix0 + pix % PW;
+                    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + k < NL && idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                        v[k] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + cc * 8 + 4 * q);
+                }
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int idx = tid + (k0 + k) * NTHR, pix = idx >> 1, q = idx & 1;
+                    if (k0 + k < NL && idx < TOT) {  // pixel pitch 10 words: 8-byte aligned only
+                        *reinterpret_cast<f32x2*>(P + pix * PP + 4 * q) = f32x2{v[k].x, v[k].y};
+                        *reinterpret_cast<f32x2*>(P + pix * PP + 4 * q + 2) = f32x2{v[k].z, v[k].w};
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        int pos = 0;  // compile-time after unrolling: position index 0..48 in the host's order (r, s, p, q)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int nr = r ? 3 : 4, ns = s ? 3 : 4;
+                // the phase's sub-grid of the tile's 7 x 7 patch: rows r, r+2, ..; columns s, s+2, ..
+                f32x2 d[4][4];
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) {
+                        d[ia][ib] = f32x2{0.f, 0.f};
+                        if (ia < nr && ib < ns) d[ia][ib] = *reinterpret_cast<const f32x2*>(pl + ((r + 2 * ia) * PW + s + 2 * ib) * PP);
+                    }
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    if (r) w5_bt<1>(d[0][ib], d[1][ib], d[2][ib], d[3][ib]);
+                    else w5_bt<0>(d[0][ib], d[1][ib], d[2][ib], d[3][ib]);
+                }
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia) {
+                    if (s) w5_bt<1>(d[ia][0], d[ia][1], d[ia][2], d[ia][3]);
+                    else w5_bt<0>(d[ia][0], d[ia][1], d[ia][2], d[ia][3]);
+                }
+                // positions of the phase, two at a time (independent MFMA chains)
+#pragma unroll
+                for (int q0 = 0; q0 < nr * ns; q0 += 2) {
+                    f32x4 M[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (q0 + u < nr * ns) {
+                                const f32x2 a2 = d[(q0 + u) / ns][(q0 + u) % ns], b2 = bq[(pos + u) % RING];
+                                M[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(m ? a2.y : a2.x, m ? b2.y : b2.x, M[u], 0, 0, 0);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (q0 + u < nr * ns) {
+                            // ring slot free: fetch the position RING ahead (runs on into the next chunk; the tail re-reads the last)
+                            const int nxt = min(cc * NPOS + pos + u + RING, NCH * NPOS - 1);
+                            bq[(pos + u) % RING] = bl[(size_t)(nxt * NCB) * 64];
+                            const int p = (q0 + u) / ns, q = (q0 + u) % ns;
+#pragma unroll
+                            for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+                                for (int ob = 0; ob < 2; ++ob) {
+                                    const int cf = w5_at(r, oa, p) * w5_at(s, ob, q);
+                                    if (cf == 1) Y[oa][ob] += M[u];
+                                    if (cf == -1) Y[oa][ob] -= M[u];
+                                }
+                        }
+                    pos += (q0 + 1 < nr * ns) ? 2 : 1;
+                }
+            }
+    }
+
+    const float sh = shift[cb * 16 + j];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int t = kq * 4 + rr, oty = t >> 3, otx = t & 7;  // D rows = tiles 4 kq + rr of this wave's 16
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int oy = oy0 + 4 * g + 2 * oty + oa, ox = ox0 + 2 * otx + ob;
+                float v = Y[oa][ob][rr] + sh;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (oy < Ho && ox < Wo) out[(((size_t)n * Ho + oy) * Wo + ox) * COUT + cb * 16 + j] = v;
+            }
+    }
+}
+
+template <int CIN, int COUT>
+static int launch_w5(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
+    constexpr int NG = 4 / (COUT / 16);
+    const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+    const size_t lds = (size_t)(8 * NG + 3) * 35 * 10 * sizeof(float);
+    auto kern = conv5x5s2_wino_kernel<CIN, COUT>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PMN_ERR_LAUNCH;
+    const int blocks = a.N * ((Wo + 15) / 16) * ((Ho + 4 * NG - 1) / (4 * NG));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// in [N,H,W,cin] channels-last; weights DEVICE float [cin/8][49][cout/16][64][2] (params.pack_conv5x5s2_wino); shift DEVICE
+// float[cout]; out [N,Ho,Wo,cout] with Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1 (5x5, stride 2, padding 2).
+// Supported (cin, cout): (8,16), (16,32), (32,64).
+extern "C" int pmn_conv5x5s2_wino(const float* in, const float* weights, const float* shift, float* out, int N, int H, int W,
+                                  int cin, int cout, int relu, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    WinoArgs a;
+    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 8 && cout == 16) return launch_w5<8, 16>(in, weights, shift, out, a, st);
+    if (cin == 16 && cout == 32) return launch_w5<16, 32>(in, weights, shift, out, a, st);
+    if (cin == 32 && cout == 64) return launch_w5<32, 64>(in, weights, shift, out, a, st);
+    return PMN_ERR_SHAPE;
+}

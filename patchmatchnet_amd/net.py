@@ -36,6 +36,7 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+        self.winograd5 = True  # forward_hip: conv2, conv5, conv8 (5x5 stride 2) in phase-decomposed Winograd form
         self.winograd = True  # forward_hip: conv3/4, conv6/7, conv9/10 in Winograd F(2x2,3x3) form (False = direct convolutions)
         self.mfma_convs = True  # forward_hip: conv5..conv10 on the fp32 matrix cores (False = VALU kernel for every layer)
         self.fold_fpn = True  # forward_hip: composed 1x1 convolutions (False = layer by layer, as the reference orders them)
@@ -66,6 +67,13 @@ class FeatureNet(nn.Module):
                     w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_wino"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                # conv5 / conv8: 149 / 161 us vs 196 / 218 us direct.  conv2 (8 -> 16 at full resolution) stays on the VALU kernel:
+                # its single-chunk instantiation spills and is slower (343 vs 316 us in isolation)
+                if cv.kernel_size[0] == 5 and cv.stride[0] == 2 and \
+                        (cv.in_channels, cv.out_channels) in ((16, 32), (32, 64)):
+                    w, s = params.pack_conv5x5s2_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean,
+                                                                     m.bn.running_var), eps=m.bn.eps)
+                    pk[f"conv{i}_wino5"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             for name in ("output1", "inner1", "inner2", "output2", "output3"):
                 m = getattr(self, name)
                 w, s = params.pack_conv(m.weight, bias=m.bias)
@@ -96,6 +104,8 @@ class FeatureNet(nn.Module):
                 continue
             if self.winograd and f"conv{i}_wino" in pk:  # 3x3 stride-1 layers: Winograd F(2x2,3x3) on the matrix cores
                 t = ops.conv3x3_wino(t, *pk[f"conv{i}_wino"], relu=True)
+            elif self.winograd5 and f"conv{i}_wino5" in pk:  # 5x5 stride-2 layers: four parity sub-convolutions in Winograd form
+                t = ops.conv5x5s2_wino(t, *pk[f"conv{i}_wino5"], relu=True)
             elif self.mfma_convs and f"conv{i}_mfma" in pk:  # wide layers: implicit GEMM on the matrix cores
                 t = ops.conv2d_mfma(t, *pk[f"conv{i}_mfma"], k, s, p, relu=True)
             else:

@@ -405,6 +405,22 @@ def conv3x3_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, re
     return out
 
 
+def conv5x5s2_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """pmn_conv5x5s2_wino: 5x5 / stride 2 / padding 2 convolution + folded-BN shift + ReLU in phase-decomposed Winograd form on
+    the matrix cores; x [N,H,W,cin] channels-last, weights from params.pack_conv5x5s2_wino -> [N,(H-1)//2+1,(W-1)//2+1,cout]."""
+    for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
+        _dev(t_, n_)
+    N, H, W, cin = x.shape
+    cout = shift.shape[0]
+    if tuple(weights.shape) != (cin // 8, 49, cout // 16, 64, 2):
+        raise PmnError("conv5x5s2_wino: weights are not in pack_conv5x5s2_wino layout for this input")
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv5x5s2_wino(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, H, W, cin,
+                                            cout, 1 if relu else 0, _stream(x)), "pmn_conv5x5s2_wino")
+    return out
+
+
 def pointwise_split_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int):
     """pmn_conv2d_mfma, 1x1 form: out = x @ W + shift on the matrix cores with the output channels split between two
     channels-last tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights from

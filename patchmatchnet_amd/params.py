@@ -185,6 +185,42 @@ def pack_conv_wino(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS
     return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
 
 
+_WINO_G2 = np.array([[1.0, 0.0], [1.0, 1.0], [0.0, 1.0]])  # F(2,2): m1 = (d0-d1) g0, m2 = d1 (g0+g1), m3 = (d1-d2) g1
+
+
+def pack_conv5x5s2_wino(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
+    """5x5 Conv2d weight [cout,cin,5,5] of a stride-2 / padding-2 layer, (cin,cout) in {(8,16),(16,32),(32,64)} (+ BatchNorm2d
+    tensors or a conv bias) -> (float32 [cin/8, 49, cout/16, 64, 2], float32 [cout]) for pmn_conv5x5s2_wino.  The kernel splits
+    the convolution into the four parity sub-convolutions W_rs[a,b] = w[2a+r, 2b+s]; their filter transforms G_r W_rs G_s^T
+    (G = F(2,3) matrix for the even / 3-tap phase, F(2,2) matrix for the odd / 2-tap phase; float64, BatchNorm scale folded in
+    first) are enumerated as positions (r, s, p, q) in that nesting order, and lane (j = lane&15, kq = lane>>4) of output-channel
+    block cb reads the two values U[pos][cin = 8cc + 2kq + m][cout = 16cb + j], m = 0, 1."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if K != 5 or (cin, cout) not in ((8, 16), (16, 32), (32, 64)):
+        raise ValueError("pack_conv5x5s2_wino: 5x5 with (cin, cout) in {(8,16), (16,32), (32,64)}")
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        s = g / np.sqrt(v + eps)
+        w = w * s[:, None, None, None]
+        shift = b - m * s
+    elif bias is not None:
+        shift = _np64(bias)
+    else:
+        shift = np.zeros(cout)
+    gm = {0: _WINO_G, 1: _WINO_G2}
+    U = []
+    for r in (0, 1):
+        for s_ in (0, 1):
+            u = np.einsum("pa,kcab,qb->pqck", gm[r], w[:, :, r::2, s_::2], gm[s_])  # [nr, ns, cin, cout]
+            U.append(u.reshape(-1, cin, cout))
+    U = np.concatenate(U, 0)  # [49, cin, cout]
+    assert U.shape[0] == 49
+    # cin = 8cc + 2kq + m, cout = 16cb + j  ->  [cc][pos][cb][kq*16 + j][m]
+    t = U.reshape(49, cin // 8, 4, 2, cout // 16, 16).transpose(1, 0, 4, 2, 5, 3).reshape(cin // 8, 49, cout // 16, 64, 2)
+    return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

@@ -38,4 +38,9 @@ for cin, cout, K, s, H, W in layers:
         ww, sw = torch.from_numpy(ww).to(dev), torch.from_numpy(sw).to(dev)
         t_w = timeit(lambda: ops.conv3x3_wino(x, ww, sw, relu=True))
         line += f" | wino {t_w:7.1f} us {gf / t_w * 1e3:6.1f} TF/s(direct-equivalent)"
+    if K == 5 and s == 2 and (cin, cout) in ((8, 16), (16, 32), (32, 64)):
+        w5, s5 = PP.pack_conv5x5s2_wino(wt)
+        w5, s5 = torch.from_numpy(w5).to(dev), torch.from_numpy(s5).to(dev)
+        t_w = timeit(lambda: ops.conv5x5s2_wino(x, w5, s5, relu=True))
+        line += f" | wino {t_w:7.1f} us {gf / t_w * 1e3:6.1f} TF/s(direct-equivalent)"
     print(line, flush=True)

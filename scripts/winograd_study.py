@@ -47,3 +47,41 @@ with torch.no_grad():
         scale = ref.abs().max()
         print(f"conv{i}: {tuple(xin.shape)} -> direct fp32 max err {float((d32 - ref).abs().max() / scale):.2e}   "
               f"winograd fp32 max err {float((w32 - ref).abs().max() / scale):.2e}   rms {float(((w32 - ref) ** 2).mean().sqrt() / scale):.2e}")
+
+# ---- 5x5 stride-2 layers (conv2, conv5, conv8): phase decomposition into four stride-1 sub-convolutions (3x3, 3x2, 2x3, 2x2 taps)
+# each in Winograd form F(2, 3) / F(2, 2) per dimension: 49 instead of 100 multiplies per 2x2 output tile and input channel.
+G3 = torch.tensor([[1, 0], [1, 1], [0, 1]], dtype=torch.float64)
+Bt3 = torch.tensor([[1, -1, 0], [0, 1, 0], [0, 1, -1]], dtype=torch.float64)
+At3 = torch.tensor([[1, 1, 0], [0, 1, -1]], dtype=torch.float64)
+GS, BS, AS = {0: G, 1: G3}, {0: Bt, 1: Bt3}, {0: At, 1: At3}
+
+def winograd_conv5s2(x, w, dtype):
+    """x [N,C,H,W] with H, W multiples of 4; w [K,C,5,5]; padding 2, stride 2."""
+    N, C, H, W = x.shape
+    xp = F.pad(x.to(dtype), (2, 2 + 4, 2, 2 + 4))
+    out = 0
+    for r in (0, 1):
+        for s in (0, 1):
+            sub = w.double()[:, :, r::2, s::2]
+            U = (GS[r] @ sub @ GS[s].t()).to(dtype)                            # [K,C,nr,ns]
+            X = xp[:, :, r::2, s::2]                                            # phase image
+            nr, ns = BS[r].shape[0], BS[s].shape[0]
+            tiles = X.unfold(2, nr, 2).unfold(3, ns, 2)[:, :, :H // 4, :W // 4]  # [N,C,th,tw,nr,ns]
+            V = BS[r].to(dtype) @ tiles @ BS[s].t().to(dtype)
+            M = torch.einsum("kcab,nchwab->nkhwab", U, V)
+            out = out + AS[r].to(dtype) @ M @ AS[s].t().to(dtype)              # [N,K,th,tw,2,2]
+    return out.permute(0, 1, 2, 4, 3, 5).reshape(N, -1, H // 2, W // 2)
+
+with torch.no_grad():
+    for i in (2, 5, 8):
+        m = getattr(net, f"conv{i}")
+        s = m.bn.weight.double() / torch.sqrt(m.bn.running_var.double() + m.bn.eps)
+        w = m.conv.weight.double() * s[:, None, None, None]
+        xin = acts[i]
+        ref = F.conv2d(xin.double(), w, None, 2, 2)
+        d32 = F.conv2d(xin, w.float(), None, 2, 2).double()
+        w32 = winograd_conv5s2(xin, w, torch.float32).double()
+        w64 = winograd_conv5s2(xin, w, torch.float64)
+        scale = ref.abs().max()
+        print(f"conv{i} (5x5 s2): {tuple(xin.shape)} -> direct fp32 max err {float((d32 - ref).abs().max() / scale):.2e}   "
+              f"winograd fp32 max err {float((w32 - ref).abs().max() / scale):.2e}   (fp64 identity check {float((w64 - ref).abs().max() / scale):.1e})")

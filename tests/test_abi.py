@@ -205,3 +205,35 @@ def test_pack_conv_wino_layout_and_transform():
     y = At @ ((G @ w[5, 7] @ G.T) * (Bt @ d @ Bt.T)) @ At.T
     ref = np.array([[(d[a:a + 3, b:b + 3] * w[5, 7]).sum() for b in range(2)] for a in range(2)])
     np.testing.assert_allclose(y, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_pack_conv5x5s2_wino_reproduces_the_stride2_convolution():
+    """params.pack_conv5x5s2_wino: position order (r, s, p, q), lane order, and the identity itself -- one 2x2 output tile of a
+    5x5 stride-2 convolution rebuilt from the packed filter transforms and the per-phase input / output transforms."""
+    from patchmatchnet_amd import params as PR
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal((32, 16, 5, 5))
+    pk, sh = PR.pack_conv5x5s2_wino(torch.from_numpy(w))
+    assert pk.shape == (2, 49, 2, 64, 2) and sh.shape == (32,)
+    Bt = {0: np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float), 1: np.array([[1, -1, 0], [0, 1, 0], [0, 1, -1]], float)}
+    At = {0: np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float), 1: np.array([[1, 1, 0], [0, 1, -1]], float)}
+    d = rng.standard_normal((7, 7, 16))  # the 7x7 input patch of one tile, all input channels
+    y = np.zeros((2, 2, 32))
+    pos = 0
+    for r in (0, 1):
+        for s in (0, 1):
+            for p in range(Bt[r].shape[0]):
+                for q in range(Bt[s].shape[0]):
+                    v = np.einsum("a,abc,b->c", Bt[r][p], d[r::2, s::2], Bt[s][q])          # [cin]
+                    U = np.zeros((16, 32))                                                    # unpack U[pos][cin][cout]
+                    for cc in range(2):
+                        for cb in range(2):
+                            for lane in range(64):
+                                for m in range(2):
+                                    U[8 * cc + 2 * (lane >> 4) + m, 16 * cb + (lane & 15)] = pk[cc, pos, cb, lane, m]
+                    y += np.einsum("a,b,k->abk", At[r][:, p], At[s][:, q], v @ U)
+                    pos += 1
+    assert pos == 49
+    ref = np.array([[[(d[2 * a:2 * a + 5, 2 * b:2 * b + 5].transpose(2, 0, 1) * w[k]).sum() for k in range(32)] for b in range(2)]
+                    for a in range(2)])
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)

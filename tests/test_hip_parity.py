@@ -334,6 +334,32 @@ def test_conv3x3_winograd_against_torch(C, H, W):
     assert float((got - direct).abs().max() / ref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 32), (32, 64)])
+@pytest.mark.parametrize("H,W", [(37, 51), (8, 64), (150, 200)])
+def test_conv5x5s2_winograd_against_torch(cin, cout, H, W):
+    """pmn_conv5x5s2_wino (four parity sub-convolutions in Winograd form on the matrix cores) vs F.conv2d(stride 2, padding 2) +
+    BatchNorm + ReLU in float64 and vs the direct kernels; odd sizes (partial tiles, borders), batch 2."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=gen)
+    wt = 0.2 * torch.randn(cout, cin, 5, 5, generator=gen)
+    bn = (0.5 + torch.rand(cout, generator=gen), 0.1 * torch.randn(cout, generator=gen), 0.1 * torch.randn(cout, generator=gen),
+          0.5 + torch.rand(cout, generator=gen))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, 2, 2)
+    ref = torch.relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                                    False, 0.0, 1e-5))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w, sh = PP.pack_conv5x5s2_wino(wt, bn=bn)
+    got = P.ops.conv5x5s2_wino(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), relu=True)
+    assert tuple(got.shape) == (2, ref.shape[2], ref.shape[3], cout)
+    err = float((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    w2, s2 = PP.pack_conv(wt, bn=bn)
+    direct = P.ops.conv2d(xin, torch.from_numpy(w2).to(DEV), torch.from_numpy(s2).to(DEV), cout, 5, 2, 2, relu=True)
+    assert float((got - direct).abs().max() / ref.abs().max()) < 1e-5
+
+
 def test_fpn_level8_matrix_core_form_matches_valu_form():
     """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
     P = _gpu()
@@ -361,6 +387,7 @@ def test_featurenet_hip_matches_miopen(fold):
     model.feature.fold_fpn = fold
     model.feature.mfma_convs = fold
     model.feature.winograd = fold
+    model.feature.winograd5 = fold
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
