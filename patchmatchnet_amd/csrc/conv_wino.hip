@@ -359,8 +359,10 @@ __device__ __forceinline__ void w5_bt(f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __restrict__ in, const f32x2* __restrict__ wU,
                                                                const float* __restrict__ shift, float* __restrict__ out,
-                                                               const WinoArgs a, const int Ho, const int Wo) {
-    constexpr int NCB = COUT / 16, NG = 4 / NCB, NCH = CIN / 8;      // cout blocks, tile groups per workgroup, chunks of 8 channels
+                                                               const WinoArgs a, const int Ho, const int Wo, const int nch) {
+    // nch = CIN / 8 chunks of 8 input channels, passed at run time on purpose: with a compile-time single trip (conv2) hipcc
+    // flattens the chunk loop, hoists all 49 weight loads to the top and spills
+    constexpr int NCB = COUT / 16, NG = 4 / NCB;                      // cout blocks, tile groups per workgroup
     constexpr int PH = 8 * NG + 3, PW = 35, PP = 10;                  // patch rows / cols / words per pixel (8 channels + 2 pad)
     constexpr int NPOS = 49, RING = 7, NTHR = 256;  // 49 % RING == 0: a position keeps its ring slot from chunk to chunk
     extern __shared__ float4 w5_lds4[];
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
     const float* pl = P + ((8 * g + 4 * ty) * PW + 4 * tx) * PP + 2 * kq;
 
 #pragma unroll 1
-    for (int cc = 0; cc < NCH; ++cc) {
+    for (int cc = 0; cc < nch; ++cc) {
         if (cc) __syncthreads();  // every wave is done with the previous chunk's patch
         {   // patch: PH x 35 pixels x 2 channel quads; at most SB loads of a thread in flight per batch (register budget)
             constexpr int TOT = PH * PW * 2, NL = (TOT + NTHR - 1) / NTHR, SB = 5;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
                     for (int u = 0; u < 2; ++u)
                         if (q0 + u < nr * ns) {
                             // ring slot free: fetch the position RING ahead (runs on into the next chunk; the tail re-reads the last)
-                            const int nxt = min(cc * NPOS + pos + u + RING, NCH * NPOS - 1);
+                            const int nxt = min(cc * NPOS + pos + u + RING, nch * NPOS - 1);
                             bq[(pos + u) % RING] = bl[(size_t)(nxt * NCB) * 64];
                             const int p = (q0 + u) / ns, q = (q0 + u) % ns;
 #pragma unroll
@@ -500,7 +502,8 @@ static int launch_w5(const float* in, const float* w, const float* shift, float*
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((Wo + 15) / 16) * ((Ho + 4 * NG - 1) / (4 * NG));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo,
+                       CIN / 8);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

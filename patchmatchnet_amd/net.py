@@ -67,10 +67,8 @@ class FeatureNet(nn.Module):
                     w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_wino"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                # conv5 / conv8: 149 / 161 us vs 196 / 218 us direct.  conv2 (8 -> 16 at full resolution) stays on the VALU kernel:
-                # its single-chunk instantiation spills and is slower (343 vs 316 us in isolation)
                 if cv.kernel_size[0] == 5 and cv.stride[0] == 2 and \
-                        (cv.in_channels, cv.out_channels) in ((16, 32), (32, 64)):
+                        (cv.in_channels, cv.out_channels) in ((8, 16), (16, 32), (32, 64)):
                     w, s = params.pack_conv5x5s2_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean,
                                                                      m.bn.running_var), eps=m.bn.eps)
                     pk[f"conv{i}_wino5"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
