@@ -85,3 +85,31 @@ with torch.no_grad():
         scale = ref.abs().max()
         print(f"conv{i} (5x5 s2): {tuple(xin.shape)} -> direct fp32 max err {float((d32 - ref).abs().max() / scale):.2e}   "
               f"winograd fp32 max err {float((w32 - ref).abs().max() / scale):.2e}   (fp64 identity check {float((w64 - ref).abs().max() / scale):.1e})")
+
+# ---- F(4x4,3x3) for the 3x3 layers: 36 multiplies per 16 outputs (2.25 per output vs 4 for F(2x2,3x3)); fp32 error check
+G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+Bt6 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+At6 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+
+def winograd43(x, w, dtype):
+    N, C, H, W = x.shape
+    U = (G6 @ w.double() @ G6.t()).to(dtype)
+    xp = F.pad(x.to(dtype), (1, 1 + 4, 1, 1 + 4))
+    tiles = xp.unfold(2, 6, 4).unfold(3, 6, 4)[:, :, :(H + 3) // 4, :(W + 3) // 4]
+    V = Bt6.to(dtype) @ tiles @ Bt6.t().to(dtype)
+    M = torch.einsum("kcab,nchwab->nkhwab", U, V)
+    Y = At6.to(dtype) @ M @ At6.t().to(dtype)
+    th, tw = Y.shape[2], Y.shape[3]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, -1, th * 4, tw * 4)[:, :, :H, :W]
+
+with torch.no_grad():
+    for i in (6, 7, 9, 10):
+        m = getattr(net, f"conv{i}")
+        s = m.bn.weight.double() / torch.sqrt(m.bn.running_var.double() + m.bn.eps)
+        w = m.conv.weight.double() * s[:, None, None, None]
+        xin = acts[i]
+        ref = F.conv2d(xin.double(), w, None, 1, 1)
+        w32 = winograd43(xin, w, torch.float32).double()
+        w64 = winograd43(xin, w, torch.float64)
+        scale = ref.abs().max()
+        print(f"conv{i} F(4x4,3x3): fp32 max err {float((w32 - ref).abs().max() / scale):.2e}   (fp64 identity check {float((w64 - ref).abs().max() / scale):.1e})")
