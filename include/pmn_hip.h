@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 10
+#define PMN_ABI_VERSION 11
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -207,6 +207,18 @@ int pmn_stem(const float *img, const float *w0, const float *s0, const float *w1
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */
 int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, const float *depth, int B, int C,
                                int D, int h, int w, int hs, int ws, float *warped, void *stream);
+
+/* Process-wide tuning of pmn_warp_correlate (diagnostics / benchmarking; defaults are the measured best):
+ *   key 1: kernel family.  bit 0 = windowed kernels where they cover the shape (0 = always the streaming kernels of
+ *          gather_corr.hip); bit 4 = the first windowed form (gather_win.hip) instead of the lane = item engine
+ *          (gather_lane.hip); bits 2 / 3 = keep the streaming kernel for the PixelwiseNet / the known-weights launches;
+ *          bit 1 = gather_win.hip without the per-lane channel-quad rotation (bank-conflict A/B);
+ *   key 4: bytes of LDS each wave of gather_lane.hip may use for its source-map window (multiple of 1024, 1024..36864);
+ *   key 6: gather_lane.hip build, 3 (168 registers, 3 waves per SIMD) or 2 (256 registers);
+ *   keys 0, 2: window bytes of gather_win.hip (known-weights / PixelwiseNet kernels); keys 3, 5: timing ablations of
+ *          gather_win.hip / gather_lane.hip (non-zero values skip work: results are then meaningless).
+ * All kernel families compute bit-identical results (tests/test_gather_win.py).  Not thread-safe against concurrent launches. */
+int pmn_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

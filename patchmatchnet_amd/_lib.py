@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -48,6 +48,7 @@ SIGNATURES = {
     "pmn_stage_projections": [_fp, _fp, _i, _i, _i, _f, _fp, _s],
     "pmn_stem": [_fp] * 6 + [_i] * 3 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
+    "pmn_set_tuning": [_i, _i],
 }
 
 _LIB: Optional[ctypes.CDLL] = None

@@ -27,113 +27,7 @@
 //                   the weighted sums in its own registers.
 //     The [C,D,h,w] warped volume and the per-view [G,D,h,w] similarity never touch HBM.
 //   * no MFMA: ~10 flop per gathered float, no dense contraction worth a matrix core (the MLPs are 16x8 / 8x16).
-#include <cstdlib>
-#include <cstring>
-
-#include "pmn_common.hpp"
-
-enum { MODE_VIEWS = 0, MODE_PIXELWISE = 1, MODE_NEIGHBOR = 2 };
-
-struct GatherArgs {
-    const float* ref;      // [B,h,w,C]
-    const float* src;      // [N,B,hs,ws,C]
-    const float* proj;     // [B,N,4,4]
-    const float* depth;    // [B,D,h,w]
-    const float* offsets;  // [B,2K,h,w]   (MODE_NEIGHBOR)
-    const float* vw_in;    // [B,N,h>>s,w>>s]
-    const float* mlp_a;    // device float[PMN_MLP_FLOATS]: similarity_net | feature_weight_net
-    const float* mlp_b;    // device float[PMN_MLP_FLOATS]: pixel_wise_net
-    float* vw_out;         // [B,N,h,w]
-    int* vw_argmax;        // [B,N,h,w] or null
-    float* sim_out;        // [B,G,D,h,w] or null
-    float* out;            // [B,D,h,w]
-    int B, N, D, h, w, hs, ws, vw_shift, ntiles;
-    int table[2 * PMN_MAX_NEIGHBORS];
-};
-
-#define MLP_LDS_FLOATS PMN_MLP_FLOATS  // 340: a float4 multiple
-
-__device__ __forceinline__ float pmn_pair_swap(float v) {
-    // lane l <-> lane l^1 through DPP quad_perm [1,0,3,2]
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-}
-
-// Pointwise MLP G -> 16 -> 8 -> 1 for NI items at once, weights read from LDS (uniform address = broadcast read).
-// Layers 1 and 2 are fused in a ROLLED loop over the 16 hidden units: unit j of every item is produced from weight row
-// j and immediately scattered into the 8 layer-2 accumulators with column j of the second weight matrix, so no array
-// of hidden activations or of weights stays live (a fully unrolled form makes hipcc hoist all 73 row loads and spill).
-// The packed block (params.py) is laid out for exactly this walk: per unit j one 20-float record
-//   [0..7] w0[j][g] (BN folded, g < G used) | [8..15] w1[k][j] (BN folded) | [16] t0[j] | pad
-// followed by t1[8] | w2[8] | b2.  Summation orders: layer 1 over g ascending, layer 2 over j ascending, layer 3 over
-// k ascending, bias added last -- the same as the oracle's.
-template <int G, int NI>
-__device__ __forceinline__ void mlp_from_lds(const float* __restrict__ W, const float (&x)[NI][G], float (&out)[NI]) {
-    float a1[NI][8];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a1[i][k] = 0.0f;
-#pragma unroll 1
-    for (int j = 0; j < 16; ++j) {
-        const float4* rp = reinterpret_cast<const float4*>(W + 20 * j);
-        float w0[8], w1c[8];
-        {
-            const float4 r0 = rp[0];
-            w0[0] = r0.x; w0[1] = r0.y; w0[2] = r0.z; w0[3] = r0.w;
-            if (G == 8) {
-                const float4 r1 = rp[1];
-                w0[4] = r1.x; w0[5] = r1.y; w0[6] = r1.z; w0[7] = r1.w;
-            }
-            const float4 c0 = rp[2], c1 = rp[3];
-            w1c[0] = c0.x; w1c[1] = c0.y; w1c[2] = c0.z; w1c[3] = c0.w;
-            w1c[4] = c1.x; w1c[5] = c1.y; w1c[6] = c1.z; w1c[7] = c1.w;
-        }
-        const float t0 = W[20 * j + 16];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float acc = w0[0] * x[i][0];
-#pragma unroll
-            for (int g = 1; g < G; ++g) acc = fmaf(w0[g], x[i][g], acc);
-            const float hj = fmaxf(acc + t0, 0.0f);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a1[i][k] = fmaf(w1c[k], hj, a1[i][k]);
-        }
-    }
-    const float4 ta = reinterpret_cast<const float4*>(W + 320)[0], tb = reinterpret_cast<const float4*>(W + 320)[1];
-    const float4 wa = reinterpret_cast<const float4*>(W + 328)[0], wb = reinterpret_cast<const float4*>(W + 328)[1];
-    const float t1[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-    const float w2[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    const float b2 = W[336];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        float acc = w2[0] * fmaxf(a1[i][0] + t1[0], 0.0f);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) acc = fmaf(w2[k], fmaxf(a1[i][k] + t1[k], 0.0f), acc);
-        out[i] = acc + b2;
-    }
-}
-
-// NIT items in chunks of NI
-template <int G, int NIT, int NI>
-__device__ __forceinline__ void mlp_items(const float* __restrict__ W, const float (&x)[NIT][G], float (&out)[NIT]) {
-    static_assert(NIT % NI == 0, "chunk must divide the item count");
-#pragma unroll
-    for (int c = 0; c < NIT / NI; ++c) {
-        float xc[NI][G], oc[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int g = 0; g < G; ++g) xc[i][g] = x[c * NI + i][g];
-        mlp_from_lds<G, NI>(W, xc, oc);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) out[c * NI + i] = oc[i];
-    }
-}
-
-__device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
-#pragma clang fp contract(off)
-    return acc + a * b;  // two roundings, like the reference's separate mul and add kernels
-}
+#include "gather_common.hpp"
 
 // Broadcast `v` from lane SL of every aligned group of LPI lanes (SL compile-time): DPP quad_perm for 4-lane groups,
 // DPP row_newbcast for 16-lane groups (one VALU op, no LDS), ds_bpermute for 8-lane groups.
@@ -158,7 +52,6 @@ __device__ __forceinline__ float group_bcast_f(float v) {
 
 // One (pixel, hypothesis) item of the lane role: returns this lane's group-correlation value (valid in the owner lane
 // of each group; with 8-channel groups both lanes of the pair hold it).
-typedef float pmn_f2 __attribute__((ext_vector_type(2)));
 
 template <int LPI, int LPG, int CG>
 __device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, const float4 w4, const int off, const int ws,
@@ -526,18 +419,21 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             return;
         }
         // PixelwiseNet + max over D (first arg-max on ties through the ~d low word)
-        {
+        if constexpr (MODE == MODE_PIXELWISE) {
             unsigned long long best = 0ull;
 #pragma unroll
             for (int c = 0; c < NIT / NI; ++c) {
-                float xc[NI][G], r[NI];
+                static_assert(NI == 2, "PixelwiseNet is evaluated for one pair of items at a time");
+                float r[NI];
+                pmn_f2 xq[1][G], rq[1];
+                {
+                    const int da = min(dA0 + (c * NI) * DSTEP, D - 1), db = min(dA0 + (c * NI + 1) * DSTEP, D - 1);
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                    for (int g = 0; g < G; ++g) xq[0][g] = pmn_f2{simt[g * SS + da * NPIX + pixA], simt[g * SS + db * NPIX + pixA]};
                 }
-                mlp_from_lds<G, NI>(wlds_b, xc, r);
+                mlp_pairs_from_lds<G, 1>(wlds_b, xq, rq);
+                r[0] = rq[0].x;
+                r[1] = rq[0].y;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int d = dA0 + (c * NI + i) * DSTEP;
@@ -677,6 +573,16 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     a.out = cost_out;
     a.B = B; a.N = N; a.D = D; a.h = h; a.w = w; a.hs = hs; a.ws = ws;
     a.vw_shift = vw_shift;
+    // kernel family (pmn_set_tuning key 1): bit 0 = windowed kernels where they cover the shape -- the lane = item engine
+    // (gather_lane.hip) or, with bit 4, the first windowed form (gather_win.hip) -- else the streaming kernel below.  Bits 2 / 3
+    // keep the streaming kernel for the PixelwiseNet / the known-weights launches only.
+    const int flags = pmn_gather_flags();
+    const bool pixelwise = view_weights_in == nullptr;
+    if ((flags & 1) && !(flags & (pixelwise ? 4 : 8))) {
+        const int rc = (flags & 16) ? pmn_launch_gather_win(a, C, G, pixelwise, (hipStream_t)stream)
+                                    : pmn_launch_gather_lane(a, C, G, pixelwise, (hipStream_t)stream);
+        if (rc != PMN_ERR_SHAPE) return rc;
+    }
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }

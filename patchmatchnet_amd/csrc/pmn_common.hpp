@@ -63,6 +63,25 @@ __device__ __forceinline__ PmnTaps pmn_make_taps(float ix, float iy, int hs, int
     return t;
 }
 
+// The same tap set with the corner position kept as (x0, y0): the windowed gather kernel addresses an LDS window with it.
+struct PmnTapsXY {
+    int x0, y0;                // clamped north-west texel
+    float w00, w01, w10, w11;  // weights of (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
+};
+
+__device__ __forceinline__ PmnTapsXY pmn_make_taps_xy(float ix, float iy, int hs, int ws) {
+#pragma clang fp contract(off)
+    float ax, bx, ay, by;
+    PmnTapsXY t;
+    pmn_axis(ix, ws, t.x0, ax, bx);
+    pmn_axis(iy, hs, t.y0, ay, by);
+    t.w00 = ax * ay;
+    t.w01 = bx * ay;
+    t.w10 = ax * by;
+    t.w11 = bx * by;
+    return t;
+}
+
 // ---- sample positions ---------------------------------------------------------------------------------------
 
 // F.grid_sample un-normalisation (ATen grid_sampler_unnormalize)

@@ -44,6 +44,17 @@ def disable_kernel_timing():
     return [(s.elapsed_time(e), nbytes, tag) for s, e, nbytes, tag in rec]
 
 
+TUNE_WINDOW_BYTES, TUNE_FLAGS, TUNE_WINDOW_BYTES_PIXELWISE, TUNE_ABLATE = 0, 1, 2, 3
+TUNE_LANE_WINDOW_BYTES, TUNE_LANE_ABLATE, TUNE_LANE_WAVES_PER_SIMD = 4, 5, 6
+FLAG_WINDOWED, FLAG_NO_ROTATION, FLAG_STREAM_PIXELWISE, FLAG_STREAM_VIEWS, FLAG_WIN_V1 = 1, 2, 4, 8, 16
+
+
+def set_tuning(key: int, value: int) -> None:
+    """pmn_set_tuning: process-wide knobs of pmn_warp_correlate (window bytes per wave, kernel family); both kernel
+    families give bit-identical results (tests/test_gather_win.py)."""
+    check(_lib.lib().pmn_set_tuning(int(key), int(value)), "pmn_set_tuning")
+
+
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise PmnError(f"{name}: expected a torch.Tensor")

@@ -176,8 +176,9 @@ def test_cascade_with_reference_features(case):
 
 
 def test_end_to_end_from_images():
-    """FeatureNet (MIOpen) + hot path + refinement from raw images vs the reference's CPU result.  FeatureNet rounding
-    differs between MIOpen and the CPU backend and amplifies down the cascade, so the criterion is statistical."""
+    """HIP FeatureNet (the default, hip_feature_net=True: stem / Winograd / MFMA convolutions) + hot path + HIP refinement from
+    raw images vs the reference's CPU result.  FeatureNet rounding differs from the CPU backend's and amplifies down the
+    cascade, so the criterion is statistical; tests/test_fullsize_parity.py runs both FeatureNet paths and records the maxima."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
