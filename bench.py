@@ -37,6 +37,27 @@ DEFAULT_KW = dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_
                   evaluate_neighbors=[9, 9, 9])
 
 
+def warp_kernel_source_hash():
+    """sha256 over the sources of pmn_warp_correlate's kernels: profiles/pmc_traffic.json carries the hash of the tree it was
+    measured on, and ``roofline.traffic`` is only reported when that is THIS tree (a stale PMC file would be a made-up number)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("gather_corr.hip", "gather_win.hip", "gather_lane.hip", "gather_common.hpp", "pmn_common.hpp"):
+        with open(os.path.join(ROOT, "patchmatchnet_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+REFERENCE_CPU_MEASURED = {
+    # the only timing of the REAL reference that exists (BASELINE.md section 2): unmodified reference models/ imported in the
+    # authoring container, params_000007.ckpt, torch 2.10 CPU backend; it cannot be re-measured on the GPU box (nothing there
+    # may read /root/reference and its sources must not be copied into this repository)
+    "value": 0.0855, "unit": "depth-maps/s (whole PatchmatchNet.forward)", "cores": 8, "kind": "reference",
+    "sample": "1600x1200, N=5, iters (1,2,2): 11.7 s warm per depth map, Intel Xeon @ 2.10 GHz, 8 threads; measured in the "
+              "authoring container, NOT on the bench box",
+}
+
+
 def load_weights(model):
     """Reference checkpoint tensors from the committed fixture; seeded random init if the fixture is unavailable."""
     path = os.path.join(ROOT, "tests", "golden", "params_000007.npz")
@@ -86,16 +107,21 @@ def cpu_baseline(H, W, n_src):
     t0 = time.perf_counter()
     O.cascade(params, feats, intr, extr, np.array([425.0], np.float32), np.array([935.0], np.float32), noise)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
-            "sample": f"1 hot-path pass (cascade stage3->1 from feature maps, FeatureNet/refinement excluded) at "
-                      f"{W}x{H}, N={n_src}, iters (1,2,2): {dt:.1f} s on {cores} threads (C oracle, OpenMP)"}
+    return {"value": 1.0 / dt, "unit": "hot-path passes/s (cascade only: FeatureNet and Refinement excluded -- NOT comparable "
+                                       "with `value`, which is the whole forward)", "cores": cores, "kind": "port",
+            "sample": f"1 hot-path pass (cascade stage3->1 from feature maps) at {W}x{H}, N={n_src}, iters (1,2,2): {dt:.1f} s on "
+                      f"{cores} threads (C oracle, OpenMP)",
+            "reference_measured_elsewhere": REFERENCE_CPU_MEASURED,
+            "rocm_reference_denominator": "unmeasurable on the bench box: the north star's '>= 4x the reference on PyTorch-ROCm' needs "
+                                          "the reference sources, which cannot travel (DESIGN.md section 4)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--samples", type=int, default=12, help="distinct synthetic samples cycled through (SURVEY 8(d): >= 10)")
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--views", type=int, default=5, help="number of SOURCE views (reference eval.py --num_views)")
@@ -123,7 +149,7 @@ def main():
     weights = load_weights(model)
     model = model.to(device).eval()
     H, W, n_src = args.height, args.width, args.views
-    samples = make_samples(4, n_src + 1, H, W, device, rank)
+    samples = make_samples(max(args.samples, 1), n_src + 1, H, W, device, rank)
 
     def step(i):
         s = samples[i % len(samples)]
@@ -181,8 +207,13 @@ def main():
         # scripts/make_traffic_json.py for the collection + gfx950 FETCH_SIZE correction); null when not available
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tpath) and (H, W, n_src) == (1200, 1600, 5):
-            tk = json.load(open(tpath))["kernels"]
+        traffic_note = "HBM bytes per step over the same launches (rocprofv3 PMC, profiles/pmc_traffic.json)"
+        tj = json.load(open(tpath)) if os.path.isfile(tpath) else None
+        if tj is not None and tj.get("kernel_source_sha256") != warp_kernel_source_hash():
+            traffic_note = "null: profiles/pmc_traffic.json was measured on different kernel sources (hash mismatch) -- re-collect"
+            tj = None
+        if tj is not None and (H, W, n_src) == (1200, 1600, 5):
+            tk = tj["kernels"]
             try:
                 per_step = 0
                 for ms, nb, tag in recs[:len(recs) // sampled]:
@@ -197,11 +228,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
                                    f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
+                       "distinct_samples": len(samples),
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence"},
             "roofline": {"bound": "hbm", "kernel": "gather_corr_kernel (pmn_warp_correlate)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per step over the same launches (rocprofv3 PMC, profiles/pmc_traffic.json)",
+                         "traffic_unit": traffic_note,
                          "launches": len(recs), "steps_with_events": sampled,
                          "kernel_ms_per_step": round(k_ms / sampled, 4), "alg_bytes_per_step": int(k_bytes / sampled),
                          "per_shape": {k: {"ms_avg": round(v[0] / v[2], 4),

@@ -8,12 +8,16 @@ mask/*.png, fused.ply: :74-82, :257-297).
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 eval.py ...     # one process per GPU
 
 Differences from the reference, all behind its interface: the model is ``patchmatchnet_amd.PatchmatchNet`` (HIP hot
-path); with several processes the reference views are sharded round-robin across ranks (instead of nn.DataParallel)
-and each scan's maps are all-gathered over RCCL for the fusion step, which runs on the device instead of in numpy/cv2.
+path); with several processes every scan's reference views are cut into contiguous blocks, one per rank (instead of
+nn.DataParallel), each scan's maps are all-gathered over RCCL, and every rank then fuses its own block of reference views with
+one HIP kernel launch per view (pmn_fuse_view) instead of numpy/cv2; rank 0 stitches the per-rank point lists into fused.ply.
+Disk and PCIe traffic is taken off the critical path: decoded images go through pinned memory on a copy stream one sample
+ahead, finished maps leave through pinned buffers on the same stream and are written by a pool of writer threads.
 """
 import argparse
-import collections
+import concurrent.futures
 import os
+import queue
 import sys
 import time
 
@@ -53,16 +57,116 @@ def load_model(args, device):
     return model.to(device).eval()
 
 
-def _write_maps(args, sample, depth, confidence, produced):
-    depth_np = depth.detach().cpu().numpy()
-    conf_np = confidence.detach().cpu().numpy()
+class MapWriter:
+    """Finished (depth, confidence) maps leave the device asynchronously: the [2,H,W] tensor is copied into a pinned host
+    buffer on a side stream (ordered after the producing kernels by an event) and a writer thread saves the two files once
+    the copy has landed -- the main stream never waits for PCIe or the file system (the reference synchronises and writes
+    inline, eval.py:66-82; its save_bin packs a Python list per map, datasets/data_io.py:192-223).  A small pool of pinned
+    buffers bounds memory and applies back-pressure."""
+
+    def __init__(self, device, file_format: str, workers: int = 4, buffers: int = 6) -> None:
+        self.device, self.file_format = device, file_format
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="pmn-writer")
+        self.stream = torch.cuda.Stream(device)
+        self.free: "queue.Queue[torch.Tensor]" = queue.Queue()
+        self.nbuf, self.made, self.shape = buffers, 0, None
+        self.futures = []
+
+    def _buffer(self, shape):
+        if self.shape != tuple(shape):  # new map size: let the old buffers drain away
+            self.shape, self.made = tuple(shape), 0
+            self.free = queue.Queue()
+        if self.free.empty() and self.made < self.nbuf:
+            self.made += 1
+            return torch.empty(shape, dtype=torch.float32).pin_memory()
+        return self.free.get()
+
+    def submit(self, stacked: torch.Tensor, depth_path: str, conf_path: str) -> None:
+        buf = self._buffer(stacked.shape)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            buf.copy_(stacked, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        free, shape = self.free, self.shape
+
+        def write():
+            try:
+                done.synchronize()
+                for path, arr in ((depth_path, buf[0]), (conf_path, buf[1])):
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    save_map(path, arr.numpy())
+            finally:
+                if shape == tuple(buf.shape):
+                    free.put(buf)
+            return stacked  # keeps the device tensor alive until its copy has been consumed
+
+        self.futures.append(self.pool.submit(write))
+
+    def drain(self) -> None:
+        for f in self.futures:
+            f.result()  # re-raises a writer's exception
+        self.futures = []
+
+    def close(self) -> None:
+        self.drain()
+        self.pool.shutdown(wait=True)
+
+
+class DevicePrefetcher:
+    """Iterates a DataLoader one sample ahead: the next sample's tensors are copied host -> device on a side stream (from the
+    loader's pinned memory) while the current one computes; the consumer's stream waits on the copy's event only."""
+
+    def __init__(self, loader, device, keys=("images", "intrinsics", "extrinsics", "depth_min", "depth_max")) -> None:
+        self.loader, self.device, self.keys = loader, device, keys
+        self.stream = torch.cuda.Stream(device)
+
+    def _stage(self, sample):
+        out = dict(sample)
+        with torch.cuda.stream(self.stream):
+            for k in self.keys:
+                v = sample[k]
+                out[k] = [t.to(self.device, non_blocking=True) for t in v] if isinstance(v, (list, tuple)) else \
+                    v.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for k in self.keys:  # the tensors were allocated on the side stream: tell the allocator who uses them
+                v = cur[k]
+                for t in (v if isinstance(v, (list, tuple)) else [v]):
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield cur
+
+
+def _seed_sample(args, dataset, sample) -> None:
+    if args.sample_seed >= 0:
+        scan = sample["scan"][0] if isinstance(sample["scan"], (list, tuple)) else sample["scan"]
+        torch.manual_seed(args.sample_seed + 1000003 * dataset.scan_index(scan) + int(sample["ref_view"][0]))
+
+
+def _write_maps(args, sample, depth, confidence, produced, writer):
     for b, filename in enumerate(sample["filename"]):
-        for kind, arr in (("depth_est", depth_np[b, 0]), ("confidence", conf_np[b])):
-            path = os.path.join(args.output_folder, filename.format(kind, args.file_format))
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            save_map(path, np.ascontiguousarray(arr))
+        stacked = torch.stack((depth[b, 0], confidence[b]), 0)
+        writer.submit(stacked, os.path.join(args.output_folder, filename.format("depth_est", args.file_format)),
+                      os.path.join(args.output_folder, filename.format("confidence", args.file_format)))
         scan = filename.split("{}")[0].rstrip(os.sep)
-        produced[(scan, int(sample["ref_view"][b]))] = torch.stack((depth[b, 0], confidence[b]), 0)
+        produced[(scan, int(sample["ref_view"][b]))] = stacked
 
 
 def _encode_once_ok(dataset, scan, light, views):
@@ -88,6 +192,7 @@ def save_depth(args, rank, world, device):
                          scan_list=args.scan_list, num_light_idx=args.num_light_idx).shard(rank, world)
     produced = {}  # (scan, ref view) -> [2,H,W] on device, kept for the per-scan gather
     done, total = 0, len(dataset)
+    writer = MapWriter(device, args.file_format, workers=max(args.writer_threads, 1))
     with torch.no_grad():
         for (scan, light), indices in dataset.groups().items():
             views = dataset.views_of(indices)
@@ -96,13 +201,13 @@ def save_depth(args, rank, world, device):
             if not encode_once:
                 dataset.load_images = True
                 loader = DataLoader(subset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                                    drop_last=False)
-                for sample in loader:
+                                    drop_last=False, pin_memory=True)
+                for sample in DevicePrefetcher(loader, device):
                     start = time.time()
-                    depth, confidence, _ = model([im.to(device) for im in sample["images"]], sample["intrinsics"].to(device),
-                                                 sample["extrinsics"].to(device), sample["depth_min"].to(device),
-                                                 sample["depth_max"].to(device))
-                    _write_maps(args, sample, depth, confidence, produced)
+                    _seed_sample(args, dataset, sample)
+                    depth, confidence, _ = model(list(sample["images"]), sample["intrinsics"], sample["extrinsics"],
+                                                 sample["depth_min"], sample["depth_max"])
+                    _write_maps(args, sample, depth, confidence, produced, writer)
                     done += len(sample["filename"])
                     print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
                 continue
@@ -111,9 +216,9 @@ def save_depth(args, rank, world, device):
             pyramids, images = {}, {}
             refs = {dataset.metas[i][2] for i in indices}
             vloader = DataLoader(MVSViewDataset(dataset, scan, light, views), batch_size=4, shuffle=False,
-                                 num_workers=args.num_workers, drop_last=False)
-            for batch in vloader:
-                imgs = batch["image"].to(device)
+                                 num_workers=args.num_workers, drop_last=False, pin_memory=True)
+            for batch in DevicePrefetcher(vloader, device, keys=("image",)):
+                imgs = batch["image"]
                 f = model.feature.forward_hip(imgs)
                 for j, v in enumerate(batch["view"].tolist()):
                     pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
@@ -128,48 +233,67 @@ def save_depth(args, rank, world, device):
                 start = time.time()
                 ids = [int(v) for v in sample["view_ids"][0]]
                 ref_img = images[ids[0]]
+                _seed_sample(args, dataset, sample)
                 depth, confidence, _ = model([ref_img] * len(ids), sample["intrinsics"].to(device),
                                              sample["extrinsics"].to(device), sample["depth_min"].to(device),
                                              sample["depth_max"].to(device), features=[pyramids[v] for v in ids])
-                _write_maps(args, sample, depth, confidence, produced)
+                _write_maps(args, sample, depth, confidence, produced, writer)
                 done += 1
                 print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
             dataset.load_images = True
+    writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
     return produced
 
 
-def filter_depth(args, scan, produced, rank, world, device):
-    """Consistency filtering + fusion of one scan (reference eval.py:193-297).  Maps come from device memory (all-gathered
-    across ranks) when this process produced them, else from the files a previous --output_type depth run wrote."""
-    pairs = read_pair_file(os.path.join(args.input_folder, scan, "pair.txt"))
-    view_ids = sorted({r for r, _ in pairs} | {s for _, ss in pairs for s in ss})
-    views = {}
+def _scan_cameras(args, scan, view_ids):
+    cams, sizes = {}, {}
     for vid in view_ids:
-        img, h0, w0 = read_image(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(vid)),
-                                 args.image_max_dim)
+        h, w, h0, w0 = image_shape(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(vid)), args.image_max_dim)
         K, E, _ = read_cam_file(os.path.join(args.input_folder, scan, "cams/{:0>8}_cam.txt".format(vid)))
-        K[0] *= img.shape[1] / w0
-        K[1] *= img.shape[0] / h0
-        views[vid] = {"image": img, "intrinsics": K, "extrinsics": E}
+        K[0] *= w / w0
+        K[1] *= h / h0
+        cams[vid] = {"intrinsics": K, "extrinsics": E}
+        sizes[vid] = (h, w)
+    return cams, sizes
+
+
+def filter_depth(args, scan, produced, rank, world, device):
+    """Consistency filtering + fusion of one scan (reference eval.py:193-297).  The maps come from device memory (all-gathered
+    across ranks) when this run produced them, else from the files a previous --output_type depth run wrote.  Every rank fuses its
+    own block of reference views (pmn_fuse_view, one launch per view); rank 0 stitches the per-rank point lists, which arrive in
+    pair-file order because the blocks are contiguous, into fused.ply."""
+    pairs = read_pair_file(os.path.join(args.input_folder, scan, "pair.txt"))
     ref_ids = [r for r, _ in pairs]
+    view_ids = sorted(set(ref_ids) | {s for _, ss in pairs for s in ss})
+    cams, sizes = _scan_cameras(args, scan, view_ids)
+    if len(set(sizes.values())) != 1:
+        raise P.PmnError("{}: views of different sizes after --image_max_dim ({}); the fused-on-device path needs one size per "
+                         "scan".format(scan or args.input_folder, sorted(set(sizes.values()))))
+    H, W = sizes[view_ids[0]]
+    buf, slot_of = None, {}
     if produced is not None:
-        H, W = views[ref_ids[0]]["image"].shape[:2]
-        local = {vid: produced[(scan, vid)] for vid in pdist.shard_views(ref_ids, rank, world) if (scan, vid) in produced}
-        maps = pdist.gather_scan_maps(local, ref_ids, H, W, device)
-    else:
-        maps = {}
-    for vid in view_ids:
-        if vid in maps:
-            views[vid]["depth"], views[vid]["confidence"] = maps[vid][0], maps[vid][1]
-        else:
-            views[vid]["depth"] = read_map(os.path.join(args.output_folder, scan, "depth_est/{:0>8}{}".format(
-                vid, args.file_format))).squeeze(2)
-            views[vid]["confidence"] = read_map(os.path.join(args.output_folder, scan, "confidence/{:0>8}{}".format(
-                vid, args.file_format))).squeeze(2)
-    if rank != 0:
-        return
-    vertices, colors, masks = fusion.fuse_scan(views, pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                               args.geo_mask_thres, args.photo_thres, device)
+        mine = pdist.shard_views(ref_ids, rank, world)
+        missing = [vid for vid in mine if (scan, vid) not in produced]
+        if missing:
+            raise P.PmnError("{}: this rank did not produce the maps of views {} it owns".format(scan, missing))
+        buf, slot_of = pdist.gather_scan_buffer({vid: produced[(scan, vid)] for vid in mine}, ref_ids, H, W, device)
+    extra = [vid for vid in view_ids if vid not in slot_of]
+    if extra:  # fusion-only run, or a source view that is nobody's reference view: read the files
+        maps = []
+        for vid in extra:
+            d = read_map(os.path.join(args.output_folder, scan, "depth_est/{:0>8}{}".format(vid, args.file_format))).squeeze(2)
+            c = read_map(os.path.join(args.output_folder, scan, "confidence/{:0>8}{}".format(vid, args.file_format))).squeeze(2)
+            maps.append(torch.from_numpy(np.stack((d, c)).astype(np.float32)))
+        more = torch.stack(maps).to(device)
+        base = 0 if buf is None else buf.shape[0]
+        buf = more if buf is None else torch.cat((buf, more), 0)
+        slot_of.update({vid: base + i for i, vid in enumerate(extra)})
+    a, b = pdist.block_range(len(pairs), rank, world)
+    my_pairs = pairs[a:b]
+    images = {ref: read_image(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(ref)), args.image_max_dim)[0]
+              for ref, _ in my_pairs}
+    vertices, colors, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
+                                                args.geo_mask_thres, args.photo_thres)
     os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
     for ref, (photo, geo, final) in masks.items():
         save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_photo.png".format(ref)), photo)
@@ -178,8 +302,26 @@ def filter_depth(args, scan, produced, rank, world, device):
         print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
             os.path.join(args.input_folder, scan), ref, geo.mean(), photo.mean(), final.mean()))
     ply = os.path.join(args.output_folder, scan, "fused.ply")
-    fusion.write_ply(ply, vertices, colors)
-    print("saving the final model to", ply)
+    if world == 1:
+        fusion.write_ply(ply, vertices, colors)
+    else:
+        # per-rank raw vertex records next to the target; rank 0 writes the header for the total and appends the parts in rank
+        # (= pair-file) order: the same bytes a single-rank run writes
+        fusion.ply_records(vertices, colors).tofile(ply + ".part{}".format(rank))
+        torch.distributed.barrier()
+        if rank == 0:
+            parts = [ply + ".part{}".format(r) for r in range(world)]
+            total = sum(os.path.getsize(p) for p in parts) // 15
+            with open(ply, "wb") as f:
+                f.write(fusion.ply_header(total))
+                for p in parts:
+                    with open(p, "rb") as g:
+                        f.write(g.read())
+            for p in parts:
+                os.remove(p)
+        torch.distributed.barrier()
+    if rank == 0:
+        print("saving the final model to", ply)
 
 
 def build_parser():
@@ -216,6 +358,11 @@ def build_parser():
     p.add_argument("--photo_thres", type=float, default=0.5, help="threshold for photometric consistency filtering")
     # additions
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader worker processes per rank")
+    p.add_argument("--sample_seed", type=int, default=-1,
+                   help=">= 0: re-seed the device RNG per sample from (this value, scan, reference view) so the stage-3 random "
+                        "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
+                        "(-1 = one RNG stream per process, like the reference)")
+    p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
     p.add_argument("--feature_cache", type=int, default=64,
                    help="> 0: decode and encode every view of a scan ONCE per rank and keep its FeatureNet pyramid on the device "
                         "(0 = re-decode and re-encode per sample like the reference; needs --batch_size 1)")

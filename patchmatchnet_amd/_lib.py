@@ -17,6 +17,7 @@ ABI_VERSION = 11
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
+MAX_FUSE_SRC = 32
 
 _fp = ctypes.c_void_p  # device float* (passed as integer address)
 _ip = ctypes.c_void_p
@@ -49,6 +50,7 @@ SIGNATURES = {
     "pmn_stem": [_fp] * 6 + [_i] * 3 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
     "pmn_set_tuning": [_i, _i],
+    "pmn_fuse_view": [_fp, ctypes.c_longlong, _i, _hp, _i, _fp, _i, _i, _f, _f, _i, _f, _fp, _fp, _fp, _ip, _s],
 }
 
 _LIB: Optional[ctypes.CDLL] = None

@@ -1,0 +1,150 @@
+// fusion.hip -- photometric + geometric consistency of one reference view against its source views and the fused 3-D
+// points, in one kernel.
+//
+// Reference: eval.py:86-145 (reproject_with_depth), :148-190 (check_geometric_consistency), :207-281 (filter_depth: photo
+// mask, geometric mask sum, averaged depth, final mask, world points).  The reference does this per (ref, src) pair in
+// single-threaded numpy + cv2.remap over maps re-read from disk; here a thread owns one reference pixel and walks the source
+// views with the running mask count / depth sum in registers, reading the per-scan [V][2][H][W] buffer that the all-gather
+// leaves in HBM.  The numeric types follow the reference's numpy dtype flow (float32 camera matrices promoted to float64 in
+// the products, float32 casts of the map coordinates / re-projected depth and positions, float32 threshold on the relative
+// depth difference, float64 on the pixel distance) and cv2.remap's INTER_LINEAR is restated with its 1/32-pixel fixed-point
+// coordinates (OpenCV imgwarp.cpp, INTER_BITS = 5; oracle/fusion_oracle.py carries the same restatement).
+#include <cstring>
+
+#include "pmn_common.hpp"
+
+#define PMN_FUSE_REF_FLOATS 48
+#define PMN_FUSE_SRC_FLOATS 64
+
+struct FuseArgs {
+    const float* maps;     // [V][2][H][W]: slot v = (depth, confidence)
+    long long slot_stride; // floats between slots (>= 2*H*W)
+    const float* mats;     // device floats: ref block (48) + n_src blocks (64), layout in include/pmn_hip.h
+    unsigned char* masks;  // [3][H][W]: photo, geo, final
+    float* xyz;            // [H][W][3] world points (meaningful where final)
+    double* depth_avg;     // [H][W] or null
+    int* geo_sum;          // [H][W] or null
+    int ref_slot, n_src, H, W, geo_mask_thres;
+    float geo_pixel_thres, geo_depth_thres, photo_thres;
+    int src_slot[PMN_MAX_FUSE_SRC];
+};
+
+// cv2.remap(src, x, y, INTER_LINEAR), float32 single channel, BORDER_CONSTANT 0
+__device__ __forceinline__ float remap_linear_cv2(const float* __restrict__ src, int H, int W, float x, float y) {
+#pragma clang fp contract(off)
+    const float mx = x * 32.0f, my = y * 32.0f;
+    // (written so that NaN fails the test: a NaN coordinate samples nothing)
+    if (!(fabsf(mx) < 1073741824.0f) || !(fabsf(my) < 1073741824.0f)) return 0.0f;
+    const int sx = (int)rintf(mx), sy = (int)rintf(my);  // cvRound: to nearest, ties to even
+    const int ix = sx >> 5, iy = sy >> 5;
+    const float fx = (float)(sx & 31) * 0.03125f, fy = (float)(sy & 31) * 0.03125f;
+    const float w00 = (1.0f - fy) * (1.0f - fx), w01 = (1.0f - fy) * fx, w10 = fy * (1.0f - fx), w11 = fy * fx;
+    const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W, y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+    const float t00 = (x0 && y0) ? src[(size_t)iy * W + ix] : 0.0f;
+    const float t01 = (x1 && y0) ? src[(size_t)iy * W + ix + 1] : 0.0f;
+    const float t10 = (x0 && y1) ? src[(size_t)(iy + 1) * W + ix] : 0.0f;
+    const float t11 = (x1 && y1) ? src[(size_t)(iy + 1) * W + ix + 1] : 0.0f;
+    float out = t00 * w00;
+    out = out + t01 * w01;
+    out = out + t10 * w10;
+    out = out + t11 * w11;
+    return out;
+}
+
+// rows of a row-major float32 matrix times a float64 vector (numpy: the float32 matrix is promoted, the product is float64)
+__device__ __forceinline__ double dot3(const float* __restrict__ m, double a, double b, double c) {
+    return fma((double)m[2], c, fma((double)m[1], b, (double)m[0] * a));
+}
+__device__ __forceinline__ double dot4(const float* __restrict__ m, double a, double b, double c, double d) {
+    return fma((double)m[3], d, fma((double)m[2], c, fma((double)m[1], b, (double)m[0] * a)));
+}
+
+__global__ __launch_bounds__(256) void fuse_view_kernel(const FuseArgs a) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const size_t hw = (size_t)a.H * a.W, p = (size_t)y * a.W + x;
+    const float* ref = a.maps + (size_t)a.ref_slot * a.slot_stride;
+    const float d_ref = ref[p], conf = ref[hw + p];
+    const float* Kri = a.mats;        // inverse(K_ref), float32 as numpy computes it
+    const float* Kr = a.mats + 9;     // K_ref
+    const float* Eri = a.mats + 18;   // inverse(E_ref) [4][4]
+    // reference 3-D point: inverse(K_ref) @ ((x, y, 1) * depth)   (int64 grid * float32 depth -> float64)
+    const double dx = (double)x * (double)d_ref, dy = (double)y * (double)d_ref, dz = (double)d_ref;
+    const double rx = dot3(Kri, dx, dy, dz), ry = dot3(Kri + 3, dx, dy, dz), rz = dot3(Kri + 6, dx, dy, dz);
+
+    int geo_sum = 0;
+    float acc = 0.0f;
+    for (int s = 0; s < a.n_src; ++s) {
+        const float* M = a.mats + PMN_FUSE_REF_FLOATS + s * PMN_FUSE_SRC_FLOATS;
+        const float* T = M;          // E_src @ inverse(E_ref)   (float32 product, as numpy)
+        const float* Ks = M + 16;    // K_src
+        const float* Ksi = M + 25;   // inverse(K_src)
+        const float* T2 = M + 34;    // E_ref @ inverse(E_src)
+        const float* src = a.maps + (size_t)a.src_slot[s] * a.slot_stride;
+        // source 3-D point and pixel
+        const double sx = dot4(T, rx, ry, rz, 1.0), sy = dot4(T + 4, rx, ry, rz, 1.0), sz = dot4(T + 8, rx, ry, rz, 1.0);
+        const double kx = dot3(Ks, sx, sy, sz), ky = dot3(Ks + 3, sx, sy, sz), kz = dot3(Ks + 6, sx, sy, sz);
+        const double xs = kx / kz, ys = ky / kz;
+        const float sampled = remap_linear_cv2(src, a.H, a.W, (float)xs, (float)ys);
+        // back-project with the SAMPLED source depth (float64 coordinates, as the reference)
+        const double bx = xs * (double)sampled, by = ys * (double)sampled, bz = (double)sampled;
+        const double qx = dot3(Ksi, bx, by, bz), qy = dot3(Ksi + 3, bx, by, bz), qz = dot3(Ksi + 6, bx, by, bz);
+        const double wx = dot4(T2, qx, qy, qz, 1.0), wy = dot4(T2 + 4, qx, qy, qz, 1.0), wz = dot4(T2 + 8, qx, qy, qz, 1.0);
+        const float depth_rep = (float)wz;
+        const double px = dot3(Kr, wx, wy, wz), py = dot3(Kr + 3, wx, wy, wz), pz = dot3(Kr + 6, wx, wy, wz);
+        const float x_rep = (float)(px / pz), y_rep = (float)(py / pz);
+        const double ex = (double)x_rep - (double)x, ey = (double)y_rep - (double)y;
+        const double dist = sqrt(ex * ex + ey * ey);
+        const float rel = fabsf(depth_rep - d_ref) / d_ref;
+        const bool m = dist < (double)a.geo_pixel_thres && rel < a.geo_depth_thres;
+        geo_sum += m ? 1 : 0;
+        acc = acc + (m ? depth_rep : 0.0f);
+    }
+    const float total = acc + d_ref;  // float32 sums, as python's sum() over float32 arrays
+    const double avg = (double)total / (double)(geo_sum + 1);
+    const bool photo = conf > a.photo_thres, geo = geo_sum >= a.geo_mask_thres, fin = photo && geo;
+    a.masks[p] = photo;
+    a.masks[hw + p] = geo;
+    a.masks[2 * hw + p] = fin;
+    if (a.depth_avg) a.depth_avg[p] = avg;
+    if (a.geo_sum) a.geo_sum[p] = geo_sum;
+    // world point of the averaged depth
+    const double ax = (double)x * avg, ay = (double)y * avg;
+    const double cx = dot3(Kri, ax, ay, avg), cy = dot3(Kri + 3, ax, ay, avg), cz = dot3(Kri + 6, ax, ay, avg);
+    a.xyz[3 * p + 0] = (float)dot4(Eri, cx, cy, cz, 1.0);
+    a.xyz[3 * p + 1] = (float)dot4(Eri + 4, cx, cy, cz, 1.0);
+    a.xyz[3 * p + 2] = (float)dot4(Eri + 8, cx, cy, cz, 1.0);
+}
+
+extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_slot, const int* src_slots_host, int n_src,
+                             const float* mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
+                             float photo_thres, unsigned char* masks, float* xyz, double* depth_avg, int* geo_sum,
+                             void* stream) {
+    if (!maps || !mats || !masks || !xyz || (n_src > 0 && !src_slots_host)) return PMN_ERR_ARG;
+    if (H < 1 || W < 1 || n_src < 0 || ref_slot < 0 || slot_stride < 2LL * H * W) return PMN_ERR_ARG;
+    if (n_src > PMN_MAX_FUSE_SRC) return PMN_ERR_SHAPE;
+    FuseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.maps = maps;
+    a.slot_stride = slot_stride;
+    a.mats = mats;
+    a.masks = masks;
+    a.xyz = xyz;
+    a.depth_avg = depth_avg;
+    a.geo_sum = geo_sum;
+    a.ref_slot = ref_slot;
+    a.n_src = n_src;
+    a.H = H;
+    a.W = W;
+    a.geo_mask_thres = geo_mask_thres;
+    a.geo_pixel_thres = geo_pixel_thres;
+    a.geo_depth_thres = geo_depth_thres;
+    a.photo_thres = photo_thres;
+    for (int i = 0; i < n_src; ++i) {
+        if (src_slots_host[i] < 0) return PMN_ERR_ARG;
+        a.src_slot[i] = src_slots_host[i];
+    }
+    hipLaunchKernelGGL(fuse_view_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

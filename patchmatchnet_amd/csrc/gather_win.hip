@@ -599,7 +599,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_win_pixelwise_kernel(const G
 static int g_win_cap_bytes = 12 * 1024;  // LDS window per wave, MODE_VIEWS
 static int g_win_cap_pix_bytes = 8 * 1024;  // LDS window per wave, MODE_PIXELWISE (16 x 1 pixel tiles: smaller boxes)
 static int g_win_dbg = 0;                 // timing ablations (results are then meaningless), key 3
-static int g_win_flags = 1;              // bit 0: windowed kernels enabled, bit 1: quad rotation off (bank-conflict A/B)
+static int g_win_flags = 0;              // pmn_set_tuning key 1; default = the fastest measured family per launch (profiles/)
 
 int pmn_gather_flags() { return g_win_flags; }
 

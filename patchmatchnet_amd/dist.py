@@ -1,8 +1,11 @@
 """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for the CPU tests).
 
-The hot path needs no collective: reference views are independent units and are sharded round-robin across ranks
-(SURVEY.md 8(e)).  The only exchange is the per-scan all-gather of the finished depth / confidence maps, needed because
-fusing reference view r reads the maps of its source views, which other ranks produced (reference eval.py:236-237).
+The hot path needs no collective: reference views are independent units; every (scan, light) group is cut into ``world``
+CONTIGUOUS blocks of reference views (neighbouring reference views share most of their source views, so a
+block keeps a rank's per-scan feature cache effective where a round-robin deal makes every rank encode nearly the whole scan).
+The only exchange is the per-scan all-gather of the finished depth / confidence maps, needed because fusing reference view r
+reads the maps of its source views, which other ranks produced (reference eval.py:236-237); after it every rank fuses its own
+block of reference views.
 """
 from __future__ import annotations
 
@@ -25,23 +28,37 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        # PMN_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests/test_eval_gpu.py: RCCL needs a device per rank)
+        backend = os.environ.get("PMN_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
+def block_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of rank ``rank``'s block when n items are cut into ``world`` contiguous, near-equal blocks (the first
+    n % world blocks are one longer)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
 def shard_views(view_ids: List[int], rank: int, world: int) -> List[int]:
-    """Round-robin ownership of reference views: rank r owns view_ids[r::world]."""
-    return view_ids[rank::world]
+    """Block ownership of one scan's reference views (in pair-file order): rank r owns view_ids[block_range(len, r, world)].
+    MVSDataset.shard applies the same rule per (scan, light) group, so the two always agree."""
+    a, b = block_range(len(view_ids), rank, world)
+    return view_ids[a:b]
 
 
-def gather_scan_maps(local: Dict[int, torch.Tensor], view_ids: List[int], H: int, W: int, device: torch.device
-                     ) -> Dict[int, torch.Tensor]:
-    """All-gather the [2,H,W] (depth, confidence) maps of one scan.
+def gather_scan_buffer(local: Dict[int, torch.Tensor], view_ids: List[int], H: int, W: int, device: torch.device
+                       ) -> Tuple[torch.Tensor, Dict[int, int]]:
+    """All-gather the [2,H,W] (depth, confidence) maps of one scan into ONE buffer.
 
-    ``local`` holds this rank's maps keyed by view id; ``view_ids`` is the scan's full (ordered) list, owned round-robin
-    as in ``shard_views``.  Every rank contributes ceil(len/world) slots (padding slots are zero); one
-    ``all_gather_into_tensor`` moves them -- ~15 MB per 1600x1200 view, i.e. 107.5 MB per rank for a 49-view DTU scan
-    on 8 GPUs.  Returns {view id: [2,H,W]} for ALL views of the scan on every rank."""
+    ``local`` holds this rank's maps keyed by view id; ``view_ids`` is the scan's full (ordered) list, owned in blocks as in
+    ``shard_views``.  Every rank contributes ceil(len/world) slots (padding slots are zero); one ``all_gather_into_tensor``
+    moves them -- ~15 MB per 1600x1200 view, i.e. 107.5 MB per rank for a 49-view DTU scan on 8 GPUs.  Returns
+    (buffer [world * slots, 2, H, W], {view id: slot}) on every rank: what pmn_fuse_view consumes directly."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard_views(view_ids, rank, world)
@@ -50,12 +67,23 @@ def gather_scan_maps(local: Dict[int, torch.Tensor], view_ids: List[int], H: int
     for i, vid in enumerate(mine):
         send[i] = local[vid].to(device=device, dtype=torch.float32)
     if world == 1:
-        recv = send[None]
+        recv = send
+    elif dist.get_backend() == "gloo" and send.is_cuda:  # gloo moves host memory: stage through it
+        host = torch.empty((world * slots, 2, H, W), dtype=torch.float32)
+        dist.all_gather_into_tensor(host, send.cpu())
+        recv = host.to(device)
     else:
-        recv = torch.empty((world, slots, 2, H, W), dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(recv.view(world * slots, 2, H, W), send)
-    out = {}
+        recv = torch.empty((world * slots, 2, H, W), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(recv, send)
+    slot_of = {}
     for r in range(world):
         for i, vid in enumerate(shard_views(view_ids, r, world)):
-            out[vid] = recv[r, i]
-    return out
+            slot_of[vid] = r * slots + i
+    return recv, slot_of
+
+
+def gather_scan_maps(local: Dict[int, torch.Tensor], view_ids: List[int], H: int, W: int, device: torch.device
+                     ) -> Dict[int, torch.Tensor]:
+    """``gather_scan_buffer`` as {view id: [2,H,W]} for ALL views of the scan on every rank."""
+    buf, slot_of = gather_scan_buffer(local, view_ids, H, W, device)
+    return {vid: buf[s] for vid, s in slot_of.items()}

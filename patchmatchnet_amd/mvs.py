@@ -3,7 +3,7 @@
     <data_path>/<scan>/images/[light/]00000000.jpg, <scan>/cams/00000000_cam.txt, <scan>/pair.txt
 
 One sample = one reference view + its first ``num_views`` source views.  ``shard(rank, world)`` hands every rank of a
-one-process-per-GPU job its slice of the reference views; no state is shared between samples.
+one-process-per-GPU job its contiguous block of every scan's reference views; no state is shared between samples.
 """
 from __future__ import annotations
 
@@ -29,6 +29,7 @@ class MVSDataset(Dataset):
                 scans = [ln.rstrip() for ln in f.readlines()]
         else:
             scans = [""]
+        self.scans = list(scans)
         lights = [str(i) for i in range(num_light_idx)] if num_light_idx > 0 else [""]
         self.metas: List[Tuple[str, str, int, List[int]]] = []
         for scan in scans:
@@ -37,14 +38,28 @@ class MVSDataset(Dataset):
                 self.metas += [(scan, light, ref, src) for ref, src in pairs]
 
     def shard(self, rank: int, world_size: int) -> "MVSDataset":
-        """Round-robin slice of the reference views for one rank (every rank keeps the full model replica)."""
+        """This rank's reference views: within EVERY (scan, light) group the rank's contiguous block (dist.block_range), so that
+        ownership is the same function of the position inside the scan that dist.shard_views / the per-scan all-gather use --
+        whatever the number of scans and views (every rank keeps the full model replica)."""
+        from .dist import block_range
         if not 0 <= rank < world_size:
             raise ValueError("rank out of range")
-        self.metas = self.metas[rank::world_size]
+        groups: Dict[Tuple[str, str], List[Tuple[str, str, int, List[int]]]] = {}
+        for meta in self.metas:
+            groups.setdefault((meta[0], meta[1]), []).append(meta)
+        kept: List[Tuple[str, str, int, List[int]]] = []
+        for metas in groups.values():
+            a, b = block_range(len(metas), rank, world_size)
+            kept += metas[a:b]
+        self.metas = kept
         return self
 
     def __len__(self) -> int:
         return len(self.metas)
+
+    def scan_index(self, scan: str) -> int:
+        """Position of ``scan`` in the scan list (independent of sharding)."""
+        return self.scans.index(scan)
 
     def image_path(self, scan: str, light: str, vid: int) -> str:
         return os.path.join(self.data_path, scan, self.image_folder, light, "{:0>8}{}".format(vid, self.image_extension))

@@ -47,6 +47,7 @@ def disable_kernel_timing():
 TUNE_WINDOW_BYTES, TUNE_FLAGS, TUNE_WINDOW_BYTES_PIXELWISE, TUNE_ABLATE = 0, 1, 2, 3
 TUNE_LANE_WINDOW_BYTES, TUNE_LANE_ABLATE, TUNE_LANE_WAVES_PER_SIMD = 4, 5, 6
 FLAG_WINDOWED, FLAG_NO_ROTATION, FLAG_STREAM_PIXELWISE, FLAG_STREAM_VIEWS, FLAG_WIN_V1 = 1, 2, 4, 8, 16
+DEFAULT_FLAGS = 0  # the library default: streaming kernels for every launch (the fastest measured, profiles/README.md)
 
 
 def set_tuning(key: int, value: int) -> None:
@@ -558,3 +559,37 @@ def stem(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1: torch.Tensor
         check(_lib.lib().pmn_stem(img.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1.data_ptr(), s1.data_ptr(), out.data_ptr(),
                                   N, H, W, _stream(img)), "pmn_stem")
     return out
+
+
+def fuse_view(maps: torch.Tensor, ref_slot: int, src_slots: Sequence[int], mats: torch.Tensor, geo_pixel_thres: float,
+              geo_depth_thres: float, geo_mask_thres: int, photo_thres: float, want_depth_avg: bool = False,
+              want_geo_sum: bool = False):
+    """pmn_fuse_view: consistency filtering + fusion of ONE reference view (reference eval.py:86-190, :207-281).
+
+    maps [V,2,H,W] (depth, confidence of every view of the scan, e.g. the all-gathered buffer), mats = fusion.camera_block(...)
+    (device float32).  Returns (masks [3,H,W] uint8 = photo / geo / final, xyz [H,W,3] float32 world points, depth_avg [H,W]
+    float64 or None, geo_sum [H,W] int32 or None)."""
+    _dev(maps, "maps")
+    _dev(mats, "mats")
+    if maps.dim() != 4 or maps.shape[1] != 2:
+        raise PmnError("fuse_view: maps must be [V,2,H,W]")
+    V, _, H, W = maps.shape
+    n = len(src_slots)
+    if n > _lib.MAX_FUSE_SRC:
+        raise PmnError(f"fuse_view: at most {_lib.MAX_FUSE_SRC} source views per reference view")
+    if not 0 <= ref_slot < V or any(not 0 <= s < V for s in src_slots):
+        raise PmnError("fuse_view: slot out of range")
+    if mats.numel() != 48 + 64 * n:
+        raise PmnError("fuse_view: mats must hold 48 + 64 * n_src floats (fusion.camera_block)")
+    slots, slots_p = _host_i32(np.asarray(list(src_slots) if n else [0], np.int32), max(n, 1), "src_slots")
+    masks = torch.empty((3, H, W), dtype=torch.uint8, device=maps.device)
+    xyz = torch.empty((H, W, 3), dtype=torch.float32, device=maps.device)
+    davg = torch.empty((H, W), dtype=torch.float64, device=maps.device) if want_depth_avg else None
+    gsum = torch.empty((H, W), dtype=torch.int32, device=maps.device) if want_geo_sum else None
+    with torch.cuda.device(maps.device):
+        check(_lib.lib().pmn_fuse_view(maps.data_ptr(), 2 * H * W, int(ref_slot), slots_p, n, mats.data_ptr(), H, W,
+                                       float(geo_pixel_thres), float(geo_depth_thres), int(geo_mask_thres), float(photo_thres),
+                                       masks.data_ptr(), xyz.data_ptr(), _ptr(davg), _ptr(gsum), _stream(maps)),
+              "pmn_fuse_view")
+    del slots
+    return masks, xyz, davg, gsum

@@ -134,23 +134,65 @@ class Evaluation(nn.Module):
         self.softmax = nn.LogSoftmax(dim=1)
         self.similarity_net = SimilarityNet(self.G)
 
-    def forward(self, ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: torch.Tensor,
-                depth_sample: torch.Tensor, xnorm: torch.Tensor, eval_offsets: torch.Tensor, table: np.ndarray,
-                feature_weight: torch.Tensor, view_weights: torch.Tensor, vw_shift: int, interval_scale: float,
-                is_inverse: bool, debug: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Fused-form arguments (channels-last features, relative projections, raw offsets instead of grid/weight).
+    def forward(self, ref_feature: torch.Tensor, src_features: List[torch.Tensor], ref_proj: torch.Tensor,
+                src_projs: List[torch.Tensor], depth_sample: torch.Tensor, grid: Optional[torch.Tensor],
+                weight: Optional[torch.Tensor], view_weights: torch.Tensor, is_inverse: bool, *,
+                fused: Optional[dict] = None, debug: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The reference's signature and return values (models/patchmatch.py:145-239): ref_feature [B,C,h,w], src_features
+        N x [B,C,h,w], ref_proj [B,4,4], src_projs N x [B,4,4], depth_sample [B,D,h,w], grid [B,K*h,w,2] (get_grid's normalised
+        neighbour positions), weight [B,D,K,h,w] (normalised aggregation weights), view_weights [B,N,h,w] or empty, is_inverse
+        -> (depth [B,h,w], score [B,D,h,w], view_weights [B,N,h,w]).
 
-        Returns (depth [B,h,w], score [B,D,h,w], view_weights [B,N,h,w]) like the reference."""
-        N = src_nhwc.shape[0]
+        warp + group correlation + PixelwiseNet / view aggregation + the SimilarityNet MLP always run in pmn_warp_correlate.
+        What follows depends on what the caller hands over:
+          * ``grid`` / ``weight`` (a maintainer swapping this class into the reference's PatchMatch.forward): the reference's
+            own tail on the device -- grid_sample of the pointwise cost at ``grid`` (bilinear, border, align_corners=False),
+            sum over the K neighbours with ``weight``, softmax, regression (:569-577, :221-237);
+          * ``fused`` (this package's PatchMatch.forward): {xnorm, eval_offsets, table, feature_weight, interval_scale,
+            vw_shift, ref_nhwc, src_nhwc, rel_proj}: pmn_aggregate_regress recomputes grid and weight in registers from the raw
+            conv offsets instead of reading the materialised [B,D,K,h,w] tensors; grid / weight may then be None."""
+        N = len(src_features) if src_features is not None else fused["src_nhwc"].shape[0]
+        if src_features is not None and src_projs is not None and len(src_features) != len(src_projs):
+            raise AssertionError("Patchmatch Evaluation: Different number of images and projection matrices")
         have_vw = not is_empty(view_weights)
         if have_vw and view_weights.size()[1] != N:
             raise AssertionError("Patchmatch Evaluation: Different number of images and view weights")
+        f = fused or {}
+        ref_nhwc = f.get("ref_nhwc")
+        src_nhwc = f.get("src_nhwc")
+        rel_proj = f.get("rel_proj")
+        if ref_nhwc is None:
+            ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
+        if src_nhwc is None:
+            src_nhwc = ops.stack_sources_nhwc([s.detach() for s in src_features])
+        if rel_proj is None:
+            rel_proj = ops.relative_projection(src_projs, ref_proj)
+        depth_sample = depth_sample.contiguous()
         cost, vw, argmax, sim = ops.warp_correlate(
-            ref_nhwc, src_nhwc, rel_proj, depth_sample, view_weights if have_vw else None, vw_shift,
-            self.similarity_net.packed_device(), None if have_vw else self.pixel_wise_net.packed_device(), self.G,
+            ref_nhwc, src_nhwc, rel_proj.contiguous(), depth_sample, view_weights.contiguous() if have_vw else None,
+            int(f.get("vw_shift", 0)), self.similarity_net.packed_device(),
+            None if have_vw else self.pixel_wise_net.packed_device(), self.G,
             want_similarity=debug is not None, want_argmax=debug is not None and not have_vw)
-        score, depth = ops.aggregate_regress(cost, depth_sample, xnorm, feature_weight, eval_offsets, table,
-                                             interval_scale, is_inverse)
+        if fused is not None and grid is None:
+            score, depth = ops.aggregate_regress(cost, depth_sample, f["xnorm"], f["feature_weight"], f["eval_offsets"],
+                                                 f["table"], f["interval_scale"], is_inverse)
+        else:
+            if grid is None or weight is None:
+                raise PmnError("Evaluation.forward needs grid and weight (reference signature) or the fused-form arguments")
+            B, D, h, w = depth_sample.shape
+            K = grid.shape[1] // h
+            sampled = torch.nn.functional.grid_sample(cost.contiguous(), grid, mode="bilinear", padding_mode="border",
+                                                      align_corners=False).view(B, D, K, h, w)
+            score = torch.sum(sampled * weight, dim=2)
+            score = torch.exp(self.softmax(score))
+            if is_inverse:
+                index = torch.arange(0, D, 1, device=score.device).view(1, D, 1, 1)
+                index = torch.sum(index * score, dim=1)
+                inv_min = 1.0 / depth_sample[:, -1, :, :]
+                inv_max = 1.0 / depth_sample[:, 0, :, :]
+                depth = 1.0 / (inv_max + index / (D - 1) * (inv_min - inv_max))
+            else:
+                depth = torch.sum(depth_sample * score, dim=1)
         if debug is not None:
             debug.update(cost=cost, similarity=sim, view_weight_argmax=argmax)
         return depth, score, vw.detach()
@@ -285,8 +327,11 @@ class PatchMatch(nn.Module):
             rec = {} if debug is not None else None
             had_view_weights = not is_empty(view_weights)
             d, score, view_weights = self.evaluation(
-                ref_nhwc, src_nhwc, rel_proj, hyp, xnorm, eval_offsets, self._etable, feature_weight, view_weights,
-                vw_shift, self.patchmatch_interval_scale, is_inverse, debug=rec)
+                ref_feature=ref_feature, src_features=src_features, ref_proj=ref_proj, src_projs=src_projs, depth_sample=hyp,
+                grid=None, weight=None, view_weights=view_weights, is_inverse=is_inverse,
+                fused=dict(xnorm=xnorm, eval_offsets=eval_offsets, table=self._etable, feature_weight=feature_weight,
+                           interval_scale=self.patchmatch_interval_scale, vw_shift=vw_shift, ref_nhwc=ref_nhwc,
+                           src_nhwc=src_nhwc, rel_proj=rel_proj), debug=rec)
             if not had_view_weights:
                 vw_shift = 0  # weights were just computed at this stage's resolution
             if rec is not None:

@@ -15,7 +15,10 @@ import re
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
+sys.path.insert(0, root)
+from bench import warp_kernel_source_hash  # noqa: E402  (bench.py refuses a traffic file whose hash is not the tree's)
+
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc_win")
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
@@ -33,7 +36,9 @@ for k, v in vals.items():
         wk = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
         out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
 dst = os.path.join(root, "profiles", "pmc_traffic.json")
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/kernel_bench.py at cfg-2 shapes",
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_win.sh) over the replay of a real "
+                     "forward's pmn_warp_correlate launches (scripts/warp_tune.py, bench.py's sample, cfg-2)",
+           "kernel_source_sha256": warp_kernel_source_hash(),
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE under-reports wide reads by 2x)",
            "kernels": out}, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -134,7 +134,7 @@ def main():
             print(f"launch {ci}: C{C} D{D} {h}x{w} N{N} {'vw' if vw is not None else 'pixelwise':9s} {name:10s} "
                   f"median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {nbytes / med / 1e6:8.1f} GB/s(alg)  "
                   f"{'bit-identical' if same else 'DIFFERENT'}", flush=True)
-    apply(parse_config("lane12", ops))
+    ops.set_tuning(ops.TUNE_FLAGS, ops.DEFAULT_FLAGS)
     total_bytes = 0
     for a, k in calls:
         B, h, w, C = a[0].shape

@@ -13,6 +13,9 @@ Outputs (committed):
   cascade_variant_b2.npz   B=2, 48x64, 3 source views, iters (2,1,1), propagate (4,8,16), evaluate (9,17,9): exercises
                            the 4- and 17-neighbour tables, batch > 1 and propagation on stage 1.
   ops_small.npz            differentiable_warping known answers incl. negative depth and src size != ref size.
+  evaluation_io.npz        Evaluation.forward at its own boundary (models/patchmatch.py:145-239): the reference's grid / weight /
+                           depth_sample / view_weights inputs and (depth, score, view_weights) outputs of stage-3 iteration 1
+                           (PixelwiseNet) and stage-2 iteration 1 of the default cascade (``--only evaluation`` writes just this).
 """
 import os
 import sys
@@ -65,6 +68,25 @@ def dump_cascade(path, model, n_views, H, W, B=1, seed=1234):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def dump_evaluation_io(path, model, n_views=3, H=96, W=128, seed=1234):
+    """Inputs / outputs of the reference's Evaluation.forward calls (same sample as cascade_96x128_n2.npz)."""
+    imgs = refutil.synthetic_images(n_views, H, W)
+    intr, extr = refutil.synthetic_cameras(n_views, H, W)
+    dmin, dmax = np.array([425.0], np.float32), np.array([935.0], np.float32)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(seed))
+    _, _, _, tr = refutil.trace_reference_forward(
+        model, [i.clone() for i in imgs], torch.from_numpy(intr).clone(), torch.from_numpy(extr).clone(),
+        torch.from_numpy(dmin), torch.from_numpy(dmax), noise)
+    # (features / cameras of this sample are in cascade_96x128_n2.npz)
+    out = {"n_views": np.int32(n_views)}
+    for s, it in ((3, 0), (2, 0)):
+        rec = tr[s][it]
+        for k in ("depth_sample", "grid", "weight", "view_weights_in", "depth", "score", "view_weights"):
+            out[f"s{s}_it{it + 1}_{k}"] = t2n(rec[k])
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
 def dump_ops(path):
     _, _, ref_module = refutil.import_reference()
     g = torch.Generator().manual_seed(7)
@@ -95,6 +117,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     model = refutil.build_reference_model()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "evaluation":
+        dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
+        return
     sd = refutil.state_dict_numpy(model)
     p = os.path.join(HERE, "params_000007.npz")
     np.savez_compressed(p, **sd)
@@ -120,6 +145,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "params_variant.npz"), **refutil.state_dict_numpy(variant))
     dump_cascade(os.path.join(HERE, "cascade_variant_b2.npz"), variant, 4, 48, 64, B=2, seed=4321)
     dump_ops(os.path.join(HERE, "ops_small.npz"))
+    dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,44 @@ def import_reference():
     return ref_net, ref_pm, ref_module
 
 
+def import_reference_eval():
+    """The reference's eval.py (filter_depth and friends), imported by path with its absent third-party imports stubbed:
+    cv2 (remap = the oracle's restatement of cv2.remap INTER_LINEAR), plyfile, torchvision, tensorboard.  Everything else that
+    runs is the reference's own numpy code."""
+    import importlib.util
+    import types
+    from oracle import fusion_oracle as FO
+
+    saved = {k: sys.modules.get(k) for k in ("cv2", "plyfile", "torchvision", "torchvision.utils", "torch.utils.tensorboard",
+                                             "utils", "datasets", "datasets.data_io", "datasets.mvs")}
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    stub("cv2", INTER_LINEAR=1, remap=lambda src, mx, my, interpolation=None: FO.remap_linear_cv2(src, mx, my))
+    stub("plyfile", PlyData=object, PlyElement=object)
+    tv = stub("torchvision")
+    tv.utils = stub("torchvision.utils")
+    stub("torch.utils.tensorboard", SummaryWriter=object)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        spec = importlib.util.spec_from_file_location("pmn_reference_eval", os.path.join(REFERENCE_ROOT, "eval.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
 def load_reference_state_dict() -> Dict[str, torch.Tensor]:
     sd = torch.load(CHECKPOINT, map_location="cpu")["model"]
     return {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
@@ -100,6 +138,7 @@ def trace_reference_forward(model, images, intrinsics, extrinsics, depth_min, de
         def eval_pre(_m, args, kwargs, recs=recs):
             recs.append({"depth_sample": kwargs["depth_sample"].detach().clone(),
                          "weight": kwargs["weight"].detach().clone(),
+                         "grid": kwargs["grid"].detach().clone(),
                          "view_weights_in": kwargs["view_weights"].detach().clone(),
                          "pixelwise_in": []})
 

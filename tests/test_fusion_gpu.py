@@ -1,0 +1,86 @@
+"""pmn_fuse_view (csrc/fusion.hip) against the CPU restatement of the reference's consistency filtering + fusion
+(oracle/fusion_oracle.py <- reference eval.py:86-190, :207-281) on a synthetic multi-view scene, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import fusion_oracle as FO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(V, H, W, seed):
+    rng = np.random.default_rng(seed)
+    intr, extr = synth.synthetic_cameras(V, H * 2, W * 2)
+    intr = intr[0].copy()
+    intr[:, :2] *= 0.5  # cameras of the half-resolution maps
+    extr = extr[0]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    views = {}
+    for v in range(V):
+        # a slanted plane seen from every camera would need ray casting; consistency only needs plausible, mutually overlapping
+        # maps: a smooth surface around z = 650 plus noise, holes and a few outliers
+        d = 650.0 + 40.0 * np.sin(xx / 17.0 + v) * np.cos(yy / 13.0) + rng.standard_normal((H, W)) * (0.5 + 1.5 * (v % 2))
+        d = d.astype(np.float32)
+        d[rng.random((H, W)) < 0.01] = 0.0
+        d[rng.random((H, W)) < 0.01] *= 1.3
+        c = rng.random((H, W)).astype(np.float32)
+        views[v * 3 + 1] = dict(depth=d, confidence=c, intrinsics=intr[v].astype(np.float32), extrinsics=extr[v].astype(np.float32),
+                                image=rng.random((H, W, 3)).astype(np.float32))
+    return views
+
+
+@pytest.mark.parametrize("H,W,V", [(60, 80, 4), (37, 53, 3), (300, 400, 6)])
+def test_fuse_view_matches_oracle(H, W, V):
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    from patchmatchnet_amd import fusion, ops
+    views = _scene(V, H, W, seed=H + V)
+    ids = sorted(views)
+    maps = torch.stack([torch.stack((torch.from_numpy(views[v]["depth"]), torch.from_numpy(views[v]["confidence"]))) for v in ids]).to(DEV)
+    slot_of = {v: i for i, v in enumerate(ids)}
+    thr_px, thr_d, thr_n, thr_p = 1.0, 0.01, 2 if V > 3 else 1, 0.3
+    for ref in ids[:2]:
+        srcs = [s for s in ids if s != ref]
+        block = fusion.camera_block(views[ref]["intrinsics"], views[ref]["extrinsics"],
+                                    [(views[s]["intrinsics"], views[s]["extrinsics"]) for s in srcs])
+        masks, xyz, davg, gsum = ops.fuse_view(maps, slot_of[ref], [slot_of[s] for s in srcs], torch.from_numpy(block).to(DEV),
+                                               thr_px, thr_d, thr_n, thr_p, want_depth_avg=True, want_geo_sum=True)
+        torch.cuda.synchronize()
+        want = FO.fuse_view(views[ref], [views[s] for s in srcs], thr_px, thr_d, thr_n, thr_p)
+        masks, gsum, davg, xyz = masks.cpu().numpy().astype(bool), gsum.cpu().numpy(), davg.cpu().numpy(), xyz.cpu().numpy()
+        np.testing.assert_array_equal(masks[0], want["photo"])
+        # the per-source masks may flip only where a criterion sits on its threshold (float64 products summed in another order)
+        bad = gsum != want["geo_sum"]
+        assert float(bad.mean()) < 2e-3, float(bad.mean())
+        assert int(np.abs(gsum - want["geo_sum"]).max()) <= 1
+        same = ~bad
+        assert want["geo_sum"].max() >= thr_n and same.mean() > 0.99
+        np.testing.assert_array_equal(masks[1][same], want["geo"][same])
+        np.testing.assert_array_equal(masks[2][same], want["final"][same])
+        ok = same & np.isfinite(want["depth_avg"]) & (want["depth_avg"] != 0)
+        rel = np.abs(davg[ok] - want["depth_avg"][ok]) / np.abs(want["depth_avg"][ok])
+        assert rel.max() < 1e-6, float(rel.max())
+        # world points of the pixels both sides keep
+        both = masks[2] & want["final"] & same
+        idx = np.cumsum(want["final"].reshape(-1)) - 1  # position of a final pixel in the oracle's (row-major) vertex list
+        got_pts = xyz[both]
+        want_pts = want["vertices"][idx[both.reshape(-1)]]
+        assert got_pts.shape[0] > 100
+        assert np.abs(got_pts - want_pts).max() / np.abs(want_pts).max() < 1e-6
+
+
+def test_fuse_scan_product_wrapper_and_ply(tmp_path):
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    from patchmatchnet_amd import fusion
+    views = _scene(4, 48, 64, seed=1)
+    ids = sorted(views)
+    pairs = [(r, [s for s in ids if s != r][:2]) for r in ids]
+    v, c, masks = fusion.fuse_scan(views, pairs, 1.0, 0.01, 1, 0.3, torch.device(DEV))
+    vo, co, mo = FO.fuse_scan(views, pairs, 1.0, 0.01, 1, 0.3)
+    assert abs(len(v) - len(vo)) <= 0.002 * len(vo) + 2 and v.dtype == np.float32 and c.dtype == np.uint8 and len(c) == len(v)
+    agree = np.mean([np.mean(masks[r][2] == mo[r][2]) for r in ids])
+    assert agree > 0.998
+    fusion.write_ply(str(tmp_path / "f.ply"), v, c)
+    assert (tmp_path / "f.ply").stat().st_size == len(fusion.ply_header(len(v))) + 15 * len(v)

@@ -1,0 +1,80 @@
+"""CPU tests of the fusion oracle (oracle/fusion_oracle.py): its restatement of cv2.remap, the geometry on a known scene, and --
+where the reference checkout exists -- equality with the reference's own numpy code (eval.py:86-190) run on the same inputs."""
+import numpy as np
+import pytest
+
+import refutil
+from oracle import fusion_oracle as FO
+
+
+def _scene(H=48, W=64, f=80.0, shift=30.0, seed=0):
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+    E0 = np.eye(4, dtype=np.float32)
+    E1 = np.eye(4, dtype=np.float32)
+    E1[0, 3] = -shift
+    return K, E0, E1
+
+
+def test_remap_restates_cv2_inter_linear():
+    src = np.arange(30, dtype=np.float32).reshape(5, 6) ** 1.5
+    yy, xx = np.meshgrid(np.arange(5, dtype=np.float32), np.arange(6, dtype=np.float32), indexing="ij")
+    np.testing.assert_array_equal(FO.remap_linear_cv2(src, xx, yy), src)  # integer coordinates: the pixel itself
+    # coordinates are quantised to 1/32 pixel (INTER_BITS = 5), ties to even
+    x = np.full((1, 1), 2.0 + 1.0 / 64.0, np.float32)  # 64.5/32 -> cvRound(64.5) = 64 -> exactly column 2
+    assert FO.remap_linear_cv2(src, x, np.zeros((1, 1), np.float32))[0, 0] == src[0, 2]
+    x = np.full((1, 1), 2.0 + 3.0 / 64.0, np.float32)  # 65.5 -> 66 -> fx = 2/32
+    want = src[0, 2] * np.float32(1 - 2 / 32) + src[0, 3] * np.float32(2 / 32)
+    assert FO.remap_linear_cv2(src, x, np.zeros((1, 1), np.float32))[0, 0] == np.float32(want)
+    # constant (zero) border: taps outside contribute nothing, fully outside -> 0, NaN -> 0
+    assert FO.remap_linear_cv2(src, np.full((1, 1), -0.5, np.float32), np.zeros((1, 1), np.float32))[0, 0] == np.float32(0.5) * src[0, 0]
+    assert FO.remap_linear_cv2(src, np.full((1, 1), 7.0, np.float32), np.zeros((1, 1), np.float32))[0, 0] == 0
+    assert FO.remap_linear_cv2(src, np.full((1, 1), np.nan, np.float32), np.zeros((1, 1), np.float32))[0, 0] == 0
+
+
+def test_fusion_on_a_fronto_parallel_plane():
+    """Two cameras looking at the plane z = 600 (camera-0 frame): exact depth maps are mutually consistent, a corrupted one is
+    not; fused points lie on the plane."""
+    H, W, f = 48, 64, 80.0
+    K, E0, E1 = _scene(H, W, f)
+    depth = np.full((H, W), 600.0, np.float32)
+    conf = np.full((H, W), 0.9, np.float32)
+    img = np.random.default_rng(0).random((H, W, 3)).astype(np.float32)
+    views = {0: dict(depth=depth, confidence=conf, intrinsics=K, extrinsics=E0, image=img),
+             1: dict(depth=depth.copy(), confidence=conf, intrinsics=K, extrinsics=E1, image=img)}
+    v, c, masks = FO.fuse_scan(views, [(0, [1]), (1, [0])], 1.0, 0.01, 1, 0.5)
+    photo, geo, final = masks[0]
+    assert photo.all()
+    shift = f * 30.0 / 600.0  # 4 px disparity
+    inside = np.zeros((H, W), bool)
+    inside[:-1, int(np.ceil(shift)) + 1: W - int(np.ceil(shift)) - 1] = True
+    assert geo[inside].all() and final[inside].all()
+    np.testing.assert_allclose(v[:, 2][: int(final.sum())], 600.0, rtol=1e-5)
+    assert c.dtype == np.uint8 and c.shape[1] == 3
+    views[1]["depth"] = depth * 1.2
+    r = FO.fuse_view(views[0], [views[1]], 1.0, 0.01, 1, 0.5)
+    assert not r["geo"].any()
+
+
+@pytest.mark.skipif(not refutil.have_reference(), reason="reference checkout not present")
+def test_oracle_equals_reference_numpy_code():
+    """The reference's own reproject_with_depth / check_geometric_consistency (imported, cv2.remap stubbed with the oracle's
+    restatement -- the one piece that cannot be pinned here) against the oracle on random cameras and noisy maps: identical."""
+    ref_eval = refutil.import_reference_eval()
+    rng = np.random.default_rng(3)
+    H, W = 40, 56
+    K0 = np.array([[70.0, 0, W / 2], [0, 72.0, H / 2], [0, 0, 1]], np.float32)
+    K1 = np.array([[75.0, 0, W / 2 + 1], [0, 74.0, H / 2 - 1], [0, 0, 1]], np.float32)
+    a = 0.07
+    E0 = np.eye(4, dtype=np.float32)
+    E1 = np.eye(4, dtype=np.float32)
+    E1[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    E1[:3, 3] = np.array([-25.0, 3.0, 8.0], np.float32)
+    d0 = (600.0 + 20.0 * rng.standard_normal((H, W))).astype(np.float32)
+    d1 = (600.0 + 20.0 * rng.standard_normal((H, W))).astype(np.float32)
+    d0[3, 4] = 0.0  # a hole: division by zero / NaN handling must match too
+    for thr_px, thr_d in ((1.0, 0.01), (2.5, 0.05)):
+        m_ref, dep_ref = ref_eval.check_geometric_consistency(d0.copy(), K0, E0, d1[:, :, None].copy(), K1, E1, thr_px, thr_d)
+        m_or, dep_or = FO.check_geometric_consistency(d0, K0, E0, d1, K1, E1, thr_px, thr_d)
+        np.testing.assert_array_equal(m_ref, m_or)
+        np.testing.assert_array_equal(dep_ref, dep_or)
+        assert m_or.any() and not m_or.all()

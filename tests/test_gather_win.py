@@ -106,7 +106,7 @@ def _compare(ops, case, C, pixelwise, vw_shift=0, caps=(12288,), seed=0):
                                              f"{flags}, wps {wps}); first at {idx}: streaming {a[tuple(idx)].item()!r} windowed "
                                              f"{b[tuple(idx)].item()!r}")
     finally:
-        ops.set_tuning(ops.TUNE_FLAGS, ops.FLAG_WINDOWED)
+        ops.set_tuning(ops.TUNE_FLAGS, ops.DEFAULT_FLAGS)
         ops.set_tuning(ops.TUNE_WINDOW_BYTES, 12288)
         ops.set_tuning(ops.TUNE_WINDOW_BYTES_PIXELWISE, 8192)
         ops.set_tuning(ops.TUNE_LANE_WINDOW_BYTES, 12288)

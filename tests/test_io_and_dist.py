@@ -1,5 +1,6 @@
-"""CPU tests of the callers either side of the hot path: on-disk formats, the sample source, rank sharding, the per-scan
-all-gather (world_size 2 over gloo) and the consistency-fusion arithmetic."""
+"""CPU tests of the callers either side of the hot path: on-disk formats, the sample source, rank sharding (one and several
+scans), the per-scan all-gather (world_size 2 over gloo).  The consistency-fusion arithmetic is in tests/test_fusion_oracle.py
+(oracle, CPU) and tests/test_fusion_gpu.py (pmn_fuse_view against it)."""
 import os
 
 import numpy as np
@@ -10,6 +11,7 @@ import torch.multiprocessing as mp
 
 import synth
 from patchmatchnet_amd import data_io, fusion
+from patchmatchnet_amd import _lib
 from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd.mvs import MVSDataset
 
@@ -85,7 +87,30 @@ def test_scan_reader_and_sharding(tmp_path):
         d = MVSDataset(str(tmp_path), num_views=2, scan_list=str(tmp_path / "list.txt")).shard(r, 3)
         seen += [m[2] for m in d.metas]
     assert sorted(seen) == [0, 1, 2, 3, 4]
-    assert pdist.shard_views([0, 1, 2, 3, 4], 1, 3) == [1, 4]
+    assert pdist.shard_views([0, 1, 2, 3, 4], 1, 3) == [2, 3]  # contiguous blocks: 2 + 2 + 1
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharding_agrees_with_the_gather_on_several_scans(tmp_path, world):
+    """Ownership must be the same function of the position INSIDE a scan on both sides -- the sample source (MVSDataset.shard)
+    and the per-scan all-gather / fusion (dist.shard_views) -- whatever the scan sizes.  (A global round-robin slice of the meta
+    list shifts by the previous scans' sizes: with 2 scans x 5 views and 2 ranks, rank 0 would own views [1, 3] of the second
+    scan while the gather expects [0, 2, 4], and fusion dies after all depth inference has run.)"""
+    synth.write_scan(str(tmp_path), "scanA", n_views=5, H=32, W=48, n_src=2)
+    synth.write_scan(str(tmp_path), "scanB", n_views=7, H=32, W=48, n_src=2)
+    synth.write_scan(str(tmp_path), "scanC", n_views=3, H=32, W=48, n_src=2)
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("scanA\nscanB\nscanC\n")
+    seen = {}
+    for r in range(world):
+        d = MVSDataset(str(tmp_path), num_views=2, scan_list=str(tmp_path / "list.txt")).shard(r, world)
+        for scan, n in (("scanA", 5), ("scanB", 7), ("scanC", 3)):
+            mine = [m[2] for m in d.metas if m[0] == scan]
+            assert mine == pdist.shard_views(list(range(n)), r, world), (scan, r)
+            seen.setdefault(scan, []).extend(mine)
+            # ... and the groups stay contiguous per scan (the encode-once path walks them group by group)
+        assert [k[0] for k in d.groups()] == [s for s in ("scanA", "scanB", "scanC") if any(m[0] == s for m in d.metas)]
+    assert {k: sorted(v) for k, v in seen.items()} == {"scanA": list(range(5)), "scanB": list(range(7)), "scanC": list(range(3))}
 
 
 def test_camera_only_samples_and_view_dataset(tmp_path):
@@ -147,36 +172,21 @@ def test_gather_single_process_is_identity():
     assert torch.equal(out[5], local[5]) and torch.equal(out[9], local[9])
 
 
-def test_fusion_on_a_fronto_parallel_plane(tmp_path):
-    """Two cameras looking at the plane z = 600 (in camera-0 frame): exact depth maps must be mutually consistent, a
-    corrupted one must not; fused points lie on the plane."""
-    H, W = 48, 64
-    f = 80.0
-    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
-    E0 = np.eye(4, dtype=np.float32)
-    E1 = np.eye(4, dtype=np.float32)
-    E1[0, 3] = -30.0  # camera 1 shifted along x; same orientation => depth of the plane is 600 in both
-    depth = np.full((H, W), 600.0, np.float32)
-    conf = np.full((H, W), 0.9, np.float32)
-    img = np.random.default_rng(0).random((H, W, 3)).astype(np.float32)
-    views = {0: dict(depth=depth, confidence=conf, intrinsics=K, extrinsics=E0, image=img),
-             1: dict(depth=depth.copy(), confidence=conf, intrinsics=K, extrinsics=E1, image=img)}
-    pairs = [(0, [1]), (1, [0])]
-    v, c, masks = fusion.fuse_scan(views, pairs, 1.0, 0.01, 1, 0.5, torch.device("cpu"))
-    photo, geo, final = masks[0]
-    assert photo.all()
-    # pixels whose projection falls inside the other image are consistent
-    shift = f * 30.0 / 600.0  # 4 px disparity towards -x in view 1 (+x in view 0)
-    inside = np.zeros((H, W), bool)
-    inside[:-1, int(np.ceil(shift)) + 1: W - int(np.ceil(shift)) - 1] = True
-    assert geo[inside].all() and final[inside].all()
-    np.testing.assert_allclose(v[:, 2][: int(final.sum())], 600.0, rtol=1e-5)
-    assert c.dtype == np.uint8 and c.shape[1] == 3
-    views[1]["depth"] = depth * 1.2  # inconsistent source depth => no geometric support
-    _, _, masks2 = fusion.fuse_scan(views, [(0, [1])], 1.0, 0.01, 1, 0.5, torch.device("cpu"))
-    assert not masks2[0][1].any()
+def test_ply_writer_layout(tmp_path):
+    v = np.random.default_rng(0).random((11, 3)).astype(np.float32)
+    c = (np.random.default_rng(1).random((11, 3)) * 255).astype(np.uint8)
     ply = str(tmp_path / "o" / "fused.ply")
     fusion.write_ply(ply, v, c)
-    head = open(ply, "rb").read(200).decode("ascii", "ignore")
-    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(v))
-    assert os.path.getsize(ply) == len(open(ply, "rb").read().split(b"end_header\n")[0]) + len(b"end_header\n") + 15 * len(v)
+    raw = open(ply, "rb").read()
+    assert raw.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 11\n")
+    body = raw.split(b"end_header\n", 1)[1]
+    assert len(body) == 15 * 11
+    rec = np.frombuffer(body, dtype=fusion.ply_records(v, c).dtype)
+    np.testing.assert_array_equal(rec["x"], v[:, 0])
+    np.testing.assert_array_equal(rec["blue"], c[:, 2])
+    assert fusion.ply_header(11) + fusion.ply_records(v, c).tobytes() == raw
+
+
+def test_fusion_has_no_cpu_path():
+    with pytest.raises(_lib.PmnError):
+        fusion.fuse_views(torch.zeros(2, 2, 4, 4), {0: 0, 1: 1}, {}, {}, [], 1.0, 0.01, 1, 0.5)
