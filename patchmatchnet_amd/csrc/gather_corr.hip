@@ -486,11 +486,6 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s ? atoi(s) : dflt;
-}
-
 template <int C, int G, int MODE, int DT, bool EXACT>
 static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     constexpr int LPI = C / 4, NPIX = PMN_BLOCK / LPI, PAD = 32 / G;
@@ -503,10 +498,13 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     lds = (lds + 15) & ~(size_t)15;
     auto kern = gather_corr_kernel<C, G, MODE, DT, EXACT>;
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
-    if (lds > 48 * 1024) {
+    static size_t lds_set = 0;  // per instantiation: largest dynamic-LDS size the attribute has been raised to (the call is a
+                                // driver round trip: once, not per launch)
+    if (lds > 48 * 1024 && lds > lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return PMN_ERR_LAUNCH;
+        lds_set = lds;
     }
     hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     PMN_CHECK_LAUNCH();

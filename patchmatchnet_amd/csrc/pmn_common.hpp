@@ -4,7 +4,9 @@
 //  * coordinate maths is compiled under `#pragma clang fp contract(off)` so hipcc does not contract it into
 //    FMAs -- the reference materialises every intermediate tensor (one rounding per op), and bit-identical
 //    sample positions make the tap sets identical to the oracle's;
-//  * divisions are IEEE (hipcc default: correctly rounded fp32 divide);
+//  * divisions are IEEE (hipcc default: correctly rounded fp32 divide) -- except the perspective division of the warp in the
+//    gather kernels and the depth-weight / normalisation of pmn_aggregate_regress, which use v_rcp_f32 + one Newton step
+//    (relative error < 4e-7: positions agree with the reference's own fp32 rounding to ~1e-4 px);
 //  * bilinear taps follow ATen's grid_sampler_2d: corner weights (x1-ix)*(y1-iy) ..., corners accumulated in
 //    the order nw, ne, sw, se, out-of-range corners contribute nothing.
 #pragma once

@@ -1,9 +1,14 @@
 """PatchmatchNet cascade on MI355X: the outer drop-in boundary (mirror of the reference's ``models/net.py`` interface).
 
 ``PatchmatchNet(...)`` takes the reference's constructor arguments, exposes the same sub-module / state-dict names
-(``feature``, ``patchmatch_1..3``, ``upsample_net``) and ``forward`` returns the same triple.  FeatureNet and Refinement
-stay ordinary PyTorch-ROCm modules (MIOpen); everything between them runs in the HIP kernels of
-``patchmatchnet_amd/csrc`` -- there is no CPU / eager fallback for that part.
+(``feature``, ``patchmatch_1..3``, ``upsample_net``) and ``forward`` returns the same triple.  Everything runs in the HIP
+kernels of ``patchmatchnet_amd/csrc`` -- the learned-PatchMatch cascade (no other implementation exists: no CPU / eager
+fallback) and, by default, FeatureNet and Refinement too (``hip_feature_net``: stem / Winograd / MFMA convolutions, folded FPN
+head, fused refinement).  FeatureNet and Refinement are also ordinary nn.Modules with the reference's parameters; with
+``hip_feature_net = False`` they run on PyTorch-ROCm / MIOpen, which is what the parity tests compare the HIP path with.
+
+INFERENCE ONLY: ``forward`` raises in training mode -- the kernels have no backward pass and the reference's train.py /
+patchmatchnet_loss have no counterpart here (out of scope).
 """
 from __future__ import annotations
 
@@ -22,7 +27,8 @@ from .patchmatch import PatchMatch
 
 class FeatureNet(nn.Module):
     """FPN feature extractor (reference models/net.py:9-70); outputs {3: [B,64,H/8,W/8], 2: [B,32,H/4,W/4],
-    1: [B,16,H/2,W/2]}.  Kept on PyTorch-ROCm."""
+    1: [B,16,H/2,W/2]}.  ``forward`` = the reference's op sequence on PyTorch-ROCm (MIOpen): the parity reference;
+    ``forward_hip`` = the same parameters through the HIP convolutions (what PatchmatchNet uses by default)."""
 
     def __init__(self) -> None:
         super().__init__()
@@ -142,7 +148,8 @@ class FeatureNet(nn.Module):
 
 
 class Refinement(nn.Module):
-    """Depth-residual refinement at full resolution (reference models/net.py:73-122).  Kept on PyTorch-ROCm."""
+    """Depth-residual refinement at full resolution (reference models/net.py:73-122).  ``forward`` = PyTorch-ROCm (parity
+    reference), ``forward_hip`` = pmn_conv2d at half resolution + the fused pmn_refine_front / pmn_refine_tail (default)."""
 
     def __init__(self) -> None:
         super().__init__()

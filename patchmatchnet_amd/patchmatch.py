@@ -4,7 +4,8 @@
 tree keeps the reference's parameter names, so ``params_000007.ckpt`` loads unchanged.  The arithmetic runs in four
 HIP kernels per iteration-independent / per-iteration step (see patchmatchnet_amd/csrc):
 
-    once per stage   propa_conv / eval_conv (MIOpen 3x3 dilated convs, kept on PyTorch-ROCm per the north star)
+    once per stage   propa_conv / eval_conv: both offset heads as ONE dilated 3x3 convolution on the matrix cores
+                     (pmn_conv2d_mfma, planar form; ``hip_offset_heads = False`` runs the nn.Conv2d modules on MIOpen)
                      pmn_nchw_to_nhwc       feature maps -> channels-last
                      pmn_feature_weight     FeatureWeightNet (+ get_grid)
     per iteration    pmn_init_hypotheses    DepthInitialization + Propagation (+ per-pixel sort)
@@ -219,7 +220,7 @@ class PatchMatch(nn.Module):
         self.depth_initialization = DepthInitialization(patchmatch_num_sample)
         self.propagation = Propagation()
         self.evaluation = Evaluation(self.G)
-        # offset heads stay on MIOpen; zero-initialised like the reference (:288-311)
+        # offset heads: parameter containers (run as HIP convolutions, see forward); zero-initialised like the reference (:288-311)
         self.propa_conv = nn.Conv2d(num_feature, max(2 * propagate_neighbors, 1), kernel_size=3, stride=1,
                                     padding=self.dilation, dilation=self.dilation, bias=True)
         nn.init.constant_(self.propa_conv.weight, 0.0)
@@ -266,7 +267,8 @@ class PatchMatch(nn.Module):
                 ) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
         """Reference arguments, plus optional extras that default to reference behaviour:
         ``depth_shift`` / ``vw_shift`` = 1 read ``depth`` / ``view_weights`` given at half resolution through the
-        nearest x2 up-sampling (skips materialising F.interpolate); ``noise`` pins the stage-3 random draw;
+        nearest x2 up-sampling (skips materialising F.interpolate; the ``view_weights`` RETURNED are then the tensor that was
+        passed in, still at its coarser resolution -- the reference returns them up-sampled); ``noise`` pins the stage-3 random draw;
         ``debug`` (a list) receives one dict of intermediates per iteration; ``ref_nhwc`` [B,h,w,C] / ``src_nhwc``
         [N,B,h,w,C] hand over channels-last copies the caller already made (one layout pass for all views); ``rel_proj``
         [B,N,4,4] hands over src_proj @ inverse(ref_proj) when the caller already has it (then ref_proj / src_projs are
