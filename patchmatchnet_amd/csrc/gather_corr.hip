@@ -136,7 +136,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
     const int items = NPIX * D;
     const int SS = items + PAD;
     const int p0 = tile * NPIX;
-    const int rcap = (MODE == MODE_VIEWS) ? 0 : NPIX * min(D, DCH);
+    const int rcap = (MODE == MODE_NEIGHBOR) ? NPIX * min(D, DCH) : 0;  // LDS tap records: FeatureWeightNet path only
 
     extern __shared__ float4 smem4[];
     float4* recw = smem4;                                         // [rcap] corner weights
@@ -367,6 +367,80 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         const char* sbase = reinterpret_cast<const char*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
                             ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * (C * 4);
         const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
+        if constexpr (MODE == MODE_PIXELWISE) {
+            // Lane role as in MODE_VIEWS: every lane projects RPL hypotheses of ITS OWN pixel, the records stay in registers and
+            // are broadcast inside the lane group by DPP when hypothesis d is gathered -- no LDS records, no barrier while the
+            // view's similarity tile is filled (round 1 walked 32 hypotheses at a time behind 4 barriers per view).
+            constexpr int RPL = DT / LPI;
+            const float xf = (float)xB, yf = (float)yB;
+            const float* P = a.proj + ((size_t)b * N + v) * 16;
+            const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx = P[3] * sxs;
+            const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty = P[7] * sys;
+            const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+            float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
+            int roff[RPL];
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int d = lc + j * LPI;
+                PmnTaps t;
+                t.off = 0;
+                t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+                if (okB && d < D) {
+                    const float dep = a.depth[((size_t)b * D + d) * hw + pB];
+                    const float pz = fmaf(rz, dep, tz);
+                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
+                        float inv = __builtin_amdgcn_rcpf(pz);
+                        inv = inv * fmaf(-pz, inv, 2.0f);
+                        t = pmn_make_taps(fmaf(rx, dep, tx) * inv, fmaf(ry, dep, ty) * inv, hs, ws);
+                    }
+                }
+                rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
+                roff[j] = t.off;
+            }
+            constexpr int NB = 2;
+#pragma unroll
+            for (int d0 = 0; d0 < DT; d0 += NB) {
+                PmnCorners cn[NB];
+                float4 wq[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (EXACT || d < D) {
+                        float4 w4;
+                        int off;
+#define PMN_BCAST_CASE(SL)                                                    \
+    case SL:                                                                  \
+        w4.x = group_bcast_f<LPI, SL>(rw00[d / LPI]);                         \
+        w4.y = group_bcast_f<LPI, SL>(rw01[d / LPI]);                         \
+        w4.z = group_bcast_f<LPI, SL>(rw10[d / LPI]);                         \
+        w4.w = group_bcast_f<LPI, SL>(rw11[d / LPI]);                         \
+        off = group_bcast_i<LPI, SL>(roff[d / LPI]);                          \
+        break;
+                        switch (d % LPI) {
+                            PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
+                            PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
+                            PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
+                            PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
+                            default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
+                        }
+#undef PMN_BCAST_CASE
+                        wq[i] = w4;
+                        cn[i] = load_corners<C>(sbase, (unsigned)off * (C * 4) + lane_bytes, row_bytes);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (EXACT || d < D) {
+                        const float s = blend_corners<LPG, CG>(cn[i], wq[i], refq);
+                        if (owner) simt[gB * SS + d * NPIX + grp] = s;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();  // this view's similarity tile is complete
+        } else
         for (int dc0 = 0; dc0 < D; dc0 += DCH) {
             const int dc1 = min(D, dc0 + DCH);
             phase_a(pose, dc0, dc1, 0);
@@ -492,7 +566,7 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     const int hw = a.h * a.w;
     a.ntiles = (hw + NPIX - 1) / NPIX;
     const int items = NPIX * a.D, SS = items + PAD;
-    const int rcap = (MODE == MODE_VIEWS) ? 0 : NPIX * (a.D < 32 ? a.D : 32);
+    const int rcap = (MODE == MODE_NEIGHBOR) ? NPIX * (a.D < 32 ? a.D : 32) : 0;
     size_t lds = (size_t)rcap * 20 + (size_t)((G * SS + 3) & ~3) * 4 + 2 * MLP_LDS_FLOATS * 4 + NPIX * 8 +
                  2 * PMN_MAX_NEIGHBORS * 4;
     lds = (lds + 15) & ~(size_t)15;
@@ -513,7 +587,7 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
 
 template <int C, int G, int MODE, int DT>
 static int launch_gather(GatherArgs& a, hipStream_t stream) {
-    if constexpr (MODE == MODE_VIEWS) {
+    if constexpr (MODE == MODE_VIEWS || MODE == MODE_PIXELWISE) {
         if (a.D == DT) return launch_gather_impl<C, G, MODE, DT, true>(a, stream);
     }
     return launch_gather_impl<C, G, MODE, DT, false>(a, stream);
