@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--th", type=int, nargs="+", default=[1, 2, 4])
     ap.add_argument("--dch", type=int, nargs="+", default=[4, 8])
     ap.add_argument("--features", default="net", choices=["net", "synth"])
+    ap.add_argument("--share", action="store_true", help="report register-level tap sharing statistics instead of windows")
     args = ap.parse_args()
     H, W, N = args.height, args.width, args.views
 
@@ -87,6 +88,20 @@ def main():
             for v in range(1, N + 1):
                 rel = proj[0, v] @ np.linalg.inv(proj[0, 0])
                 x0, y0 = tap_origin(rel, ds, h, w)
+                if args.share:
+                    # per-pixel reuse across hypotheses and across horizontally adjacent pixels (register-level tap sharing)
+                    key = y0 * 65536 + x0
+                    same_prev = (key[1:] == key[:-1]).mean()
+                    srt = np.sort(key, axis=0)
+                    distinct = 1 + (srt[1:] != srt[:-1]).sum(axis=0)
+                    cols = np.sort(y0 * 65536 * 4 + x0, axis=0)  # distinct 2x2 blocks vs distinct columns
+                    east = ((x0[:, :, 1:] == x0[:, :, :-1] + 1) & (y0[:, :, 1:] == y0[:, :, :-1])).mean()
+                    eq = ((x0[:, :, 1:] == x0[:, :, :-1]) & (y0[:, :, 1:] == y0[:, :, :-1])).mean()
+                    # union of texels over the D hypotheses of one pixel (what a lane walking its own pixel would load once)
+                    tex = set()
+                    print(f"   view {v}: NW texel same as previous hypothesis {same_prev * 100:.1f}%; distinct NW texels per pixel over D={D}: "
+                          f"mean {distinct.mean():.2f} p90 {np.percentile(distinct, 90):.0f}; next pixel NW = mine+1: {east * 100:.1f}%, = mine: {eq * 100:.1f}%")
+                    continue
                 for th in args.th:
                     for dch in args.dch:
                         if dch > D:
