@@ -62,9 +62,11 @@ class MapWriter:
     buffer on a side stream (ordered after the producing kernels by an event) and a writer thread saves the two files once
     the copy has landed -- the main stream never waits for PCIe or the file system (the reference synchronises and writes
     inline, eval.py:66-82; its save_bin packs a Python list per map, datasets/data_io.py:192-223).  A small pool of pinned
-    buffers bounds memory and applies back-pressure."""
+    buffers bounds memory and applies back-pressure.  PFM stores the rows bottom-up: the flip is done on the device, so a
+    writer thread only streams its pinned buffer into the file -- it never holds the GIL for a copy, and the GIL is what the
+    launch thread (55 kernel launches of Python per forward) lives on."""
 
-    def __init__(self, device, file_format: str, workers: int = 4, buffers: int = 6) -> None:
+    def __init__(self, device, file_format: str, workers: int = 4, buffers: int = 12) -> None:
         self.device, self.file_format = device, file_format
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="pmn-writer")
         self.stream = torch.cuda.Stream(device)
@@ -83,6 +85,9 @@ class MapWriter:
 
     def submit(self, stacked: torch.Tensor, depth_path: str, conf_path: str) -> None:
         buf = self._buffer(stacked.shape)
+        flipped = depth_path.endswith(".pfm")
+        if flipped:
+            stacked = stacked.flip(1)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
@@ -97,7 +102,7 @@ class MapWriter:
                 done.synchronize()
                 for path, arr in ((depth_path, buf[0]), (conf_path, buf[1])):
                     os.makedirs(os.path.dirname(path), exist_ok=True)
-                    save_map(path, arr.numpy())
+                    save_map(path, arr.numpy(), rows_flipped=flipped)
             finally:
                 if shape == tuple(buf.shape):
                     free.put(buf)
@@ -122,14 +127,21 @@ class DevicePrefetcher:
     def __init__(self, loader, device, keys=("images", "intrinsics", "extrinsics", "depth_min", "depth_max")) -> None:
         self.loader, self.device, self.keys = loader, device, keys
         self.stream = torch.cuda.Stream(device)
+        self.scale = torch.tensor(255.0, device=device)  # a DEVICE divisor: ATen turns division by a host scalar into a
+        #                                                  multiplication by the reciprocal, which is not numpy's x / 255
+
+    def _upload(self, t):
+        t = t.to(self.device, non_blocking=True)
+        if t.dtype == torch.uint8:  # MVSDataset.uint8_images: decoded bytes -> the float32 image read_image returns
+            t = t.to(torch.float32) / self.scale
+        return t
 
     def _stage(self, sample):
         out = dict(sample)
         with torch.cuda.stream(self.stream):
             for k in self.keys:
                 v = sample[k]
-                out[k] = [t.to(self.device, non_blocking=True) for t in v] if isinstance(v, (list, tuple)) else \
-                    v.to(self.device, non_blocking=True)
+                out[k] = [self._upload(t) for t in v] if isinstance(v, (list, tuple)) else self._upload(v)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return out, ev
@@ -190,6 +202,7 @@ def save_depth(args, rank, world, device):
     model = load_model(args, device)
     dataset = MVSDataset(data_path=args.input_folder, num_views=args.num_views, max_dim=args.image_max_dim,
                          scan_list=args.scan_list, num_light_idx=args.num_light_idx).shard(rank, world)
+    dataset.uint8_images = True  # 4x fewer PCIe bytes per image; DevicePrefetcher restores the float32 image on the device
     produced = {}  # (scan, ref view) -> [2,H,W] on device, kept for the per-scan gather
     done, total = 0, len(dataset)
     writer = MapWriter(device, args.file_format, workers=max(args.writer_threads, 1))

@@ -76,7 +76,10 @@ def lib() -> ctypes.CDLL:
         if not os.path.isfile(LIB_PATH):
             raise PmnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"or `make -C patchmatchnet_amd/csrc` -- patchmatchnet_amd has no fallback path")
-        L = ctypes.CDLL(LIB_PATH)
+        # PyDLL: the entry points only enqueue kernels (microseconds, never a synchronisation), so they are called WITHOUT
+        # releasing the GIL.  With CDLL each of the ~55 launches of a forward is a release/re-acquire, and every one of them is
+        # an opening for eval.py's writer threads to take the GIL away from the launch thread (PMN_CTYPES=cdll restores that).
+        L = (ctypes.CDLL if os.environ.get("PMN_CTYPES", "") == "cdll" else ctypes.PyDLL)(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             try:
                 fn = getattr(L, name)

@@ -201,29 +201,33 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         for (int j = 0; j < NIT; ++j) {
             const int d = dA0 + j * DSTEP;
             if (d < d_lo || d >= d_hi) continue;
-            PmnTaps t;
-            t.off = 0;
-            t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+            // (plain scalars, not a PmnTaps temporary: hipcc kept the conditionally assigned struct in scratch)
+            float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int off = 0;
             if (okA) {
                 if (MODE == MODE_NEIGHBOR) {
                     float ix, iy;
                     const float ox = a.offsets[((size_t)b * 2 * D + 2 * d) * hw + pA];
                     const float oy = a.offsets[((size_t)b * 2 * D + 2 * d + 1) * hw + pA];
                     pmn_neighbor_position((float)xA, (float)yA, tab[2 * d], tab[2 * d + 1], ox, oy, h, w, ix, iy);
-                    t = pmn_make_taps(ix, iy, hs, ws);
+                    const PmnTaps t = pmn_make_taps(ix, iy, hs, ws);
+                    w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
+                    off = t.off;
                 } else {
                     const float dep = a.depth[((size_t)b * D + d) * hw + pA];
                     const float pz = fmaf(q.rz, dep, q.tz);
                     if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
                         float inv = __builtin_amdgcn_rcpf(pz);
                         inv = inv * fmaf(-pz, inv, 2.0f);
-                        t = pmn_make_taps(fmaf(q.rx, dep, q.tx) * inv, fmaf(q.ry, dep, q.ty) * inv, hs, ws);
+                        const PmnTaps t = pmn_make_taps(fmaf(q.rx, dep, q.tx) * inv, fmaf(q.ry, dep, q.ty) * inv, hs, ws);
+                        w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
+                        off = t.off;
                     }
                 }
             }
             const int i = rec_base + (d - d_lo) * NPIX + pixA;
-            recw[i] = make_float4(t.w00, t.w01, t.w10, t.w11);
-            reco[i] = t.off;
+            recw[i] = w4;
+            reco[i] = off;
         }
     };
 
@@ -477,14 +481,22 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         // item role: this view's similarities of my items (re-read from the LDS tile in chunks of NI to keep few live)
         if (MODE == MODE_NEIGHBOR) {
             if (!okA) return;
-            float x[NIT][G], o[NIT];
+            // scalar MLP, NI items per call: on this launch the packed-pair form (mlp_items) measured 7 % SLOWER at stage 1
+            // (137.7 vs 128.5 us, same box) -- and re-pairing a float [NIT][G] array sent it through scratch
+            float o[NIT];
 #pragma unroll
-            for (int j = 0; j < NIT; ++j) {
-                const int d = min(dA0 + j * DSTEP, D - 1);
+            for (int c = 0; c < NIT / NI; ++c) {
+                float xc[NI][G], oc[NI];
 #pragma unroll
-                for (int g = 0; g < G; ++g) x[j][g] = simt[g * SS + d * NPIX + pixA];
+                for (int i = 0; i < NI; ++i) {
+                    const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                }
+                mlp_from_lds<G, NI>(wlds_a, xc, oc);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) o[c * NI + i] = oc[i];
             }
-            mlp_items<G, NIT, NI>(wlds_a, x, o);
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
                 const int d = dA0 + j * DSTEP;
@@ -538,6 +550,8 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         __syncthreads();  // vwkey / simt are rewritten by the next view
     }
 
+    if constexpr (MODE == MODE_NEIGHBOR) return;  // (its single pseudo view returned above; without this the dead tail below
+                                                  //  still costs the instantiation a scratch frame)
     if (!okA) return;
     float o[NIT];
 #pragma unroll

@@ -64,6 +64,18 @@ def read_image(filename: str, max_dim: int = -1) -> Tuple[np.ndarray, int, int]:
     return scale_to_max_dim(arr, max_dim)
 
 
+def read_image_u8(filename: str, max_dim: int = -1):
+    """The decoded RGB bytes [H,W,3] uint8 when read_image would not down-scale the file, else None.  eval.py uploads these
+    (a quarter of the float32 bytes over PCIe) and divides by 255 on the device -- the same IEEE float32 division numpy does in
+    read_image, so the network sees identical inputs (tests/test_eval_gpu.py)."""
+    with Image.open(filename) as im:
+        w0, h0 = im.size
+        if 0 < max_dim / max(h0, w0) < 1:
+            return None
+        arr = np.array(im, dtype=np.uint8)
+    return arr if arr.ndim == 3 and arr.shape[2] == 3 else None
+
+
 def save_image(filename: str, image: np.ndarray) -> None:
     """bool masks -> 0/255, float images in [0,1] -> uint8, everything else cast (reference data_io.py:50-64)."""
     if image.dtype == bool:
@@ -118,7 +130,9 @@ def read_pfm(filename: str) -> Tuple[np.ndarray, float]:
     return np.flipud(data.reshape(height, width, channels)), abs(scale)
 
 
-def save_pfm(filename: str, image: np.ndarray, scale: float = 1) -> None:
+def save_pfm(filename: str, image: np.ndarray, scale: float = 1, rows_flipped: bool = False) -> None:
+    """``rows_flipped``: ``image`` already holds the rows bottom-up (the file order) -- eval.py's writer threads get the maps
+    flipped on the device so that they only stream a pinned buffer to the file and never hold the GIL for a copy."""
     if image.dtype != np.float32:
         raise Exception("Image dtype must be float32.")
     if image.ndim == 3 and image.shape[2] == 3:
@@ -127,7 +141,7 @@ def save_pfm(filename: str, image: np.ndarray, scale: float = 1) -> None:
         magic = b"Pf\n"
     else:
         raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
-    rows = np.ascontiguousarray(np.flipud(image)).astype("<f4", copy=False)
+    rows = np.ascontiguousarray(image if rows_flipped else np.flipud(image)).astype("<f4", copy=False)
     with open(filename, "wb") as f:
         f.write(magic)
         f.write(f"{image.shape[1]} {image.shape[0]}\n".encode("utf-8"))
@@ -164,7 +178,10 @@ def save_bin(filename: str, data: np.ndarray) -> None:
         raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
     with open(filename, "wb") as f:
         f.write(f"{width}&{height}&{channels}&".encode("ascii"))
-        payload.reshape(-1, order="F").astype("<f4").tofile(f)
+        if data.ndim == 2 and data.flags.c_contiguous:
+            data.astype("<f4", copy=False).tofile(f)  # the Fortran-order flattening of the transpose IS the row-major map
+        else:
+            payload.reshape(-1, order="F").astype("<f4").tofile(f)
 
 
 def read_map(path: str, max_dim: int = -1) -> np.ndarray:
@@ -177,10 +194,11 @@ def read_map(path: str, max_dim: int = -1) -> np.ndarray:
     return scale_to_max_dim(data, max_dim)[0]
 
 
-def save_map(path: str, data: np.ndarray) -> None:
+def save_map(path: str, data: np.ndarray, rows_flipped: bool = False) -> None:
+    """``rows_flipped`` (PFM only): see save_pfm."""
     if path.endswith(".bin"):
         save_bin(path, data)
     elif path.endswith(".pfm"):
-        save_pfm(path, data)
+        save_pfm(path, data, rows_flipped=rows_flipped)
     else:
         raise Exception("Invalid input format; only pfm and bin are supported")

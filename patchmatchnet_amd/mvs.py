@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 from torch.utils.data import Dataset
 
-from .data_io import image_shape, read_cam_file, read_image, read_pair_file
+from .data_io import image_shape, read_cam_file, read_image, read_image_u8, read_pair_file
 
 
 class MVSDataset(Dataset):
@@ -24,6 +24,7 @@ class MVSDataset(Dataset):
         self.data_path, self.num_views, self.max_dim = data_path, num_views, max_dim
         self.cam_folder, self.image_folder, self.image_extension = cam_folder, image_folder, image_extension
         self.load_images = True  # False: samples carry cameras and image SHAPES only (eval.py's encode-once path)
+        self.uint8_images = False  # True: images that need no down-scaling come as uint8 [3,H,W]; the consumer divides by 255
         if os.path.isfile(scan_list):
             with open(scan_list) as f:
                 scans = [ln.rstrip() for ln in f.readlines()]
@@ -88,7 +89,11 @@ class MVSDataset(Dataset):
         for i, vid in enumerate(view_ids):
             path = self.image_path(scan, light, vid)
             if self.load_images:
-                img, h0, w0 = read_image(path, self.max_dim)
+                raw = read_image_u8(path, self.max_dim) if self.uint8_images else None
+                if raw is not None:
+                    img, h0, w0 = raw, raw.shape[0], raw.shape[1]
+                else:
+                    img, h0, w0 = read_image(path, self.max_dim)
                 images.append(np.ascontiguousarray(img.transpose(2, 0, 1)))
                 hi, wi = img.shape[0], img.shape[1]
             else:
@@ -121,5 +126,8 @@ class MVSViewDataset(Dataset):
 
     def __getitem__(self, idx: int) -> Dict:
         vid = self.view_ids[idx]
-        img, _, _ = read_image(self.parent.image_path(self.scan, self.light, vid), self.parent.max_dim)
+        path = self.parent.image_path(self.scan, self.light, vid)
+        img = read_image_u8(path, self.parent.max_dim) if self.parent.uint8_images else None
+        if img is None:
+            img, _, _ = read_image(path, self.parent.max_dim)
         return {"image": np.ascontiguousarray(img.transpose(2, 0, 1)), "view": vid}

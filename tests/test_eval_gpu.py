@@ -67,6 +67,17 @@ def test_eval_cli_end_to_end(tmp_path):
     assert float(depth.min()) >= 425.0 * 0.9 and float(depth.max()) <= 935.0 * 1.1
 
 
+def test_uint8_upload_restores_numpy_division():
+    """eval.py uploads decoded bytes and divides by 255 on the device; every byte value must give numpy's float32 x / 255.0
+    (what the reference's read_image feeds the network, datasets/data_io.py:34-47)."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    sys.path.insert(0, ROOT)
+    import eval as pm_eval
+    pre = pm_eval.DevicePrefetcher([], torch.device("cuda:0"))
+    got = pre._upload(torch.arange(256, dtype=torch.uint8)).cpu().numpy()
+    np.testing.assert_array_equal(got, np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0)
+
+
 def _run_eval(cmd_args, env_extra, cwd):
     import subprocess
     env = dict(os.environ)

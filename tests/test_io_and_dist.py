@@ -32,6 +32,9 @@ def test_pfm_roundtrip_and_layout(tmp_path):
     np.testing.assert_array_equal(data_io.read_pfm(str(tmp_path / "c.pfm"))[0], c)
     with pytest.raises(Exception):
         data_io.save_pfm(str(tmp_path / "d.pfm"), a.astype(np.float64))
+    # eval.py's writer threads hand over maps that were flipped on the device: same file, byte for byte
+    data_io.save_map(str(tmp_path / "e.pfm"), np.ascontiguousarray(a[::-1]), rows_flipped=True)
+    assert open(str(tmp_path / "e.pfm"), "rb").read() == raw
 
 
 def test_colmap_bin_roundtrip_and_layout(tmp_path):
@@ -45,6 +48,11 @@ def test_colmap_bin_roundtrip_and_layout(tmp_path):
     b = data_io.read_map(p)
     assert b.shape == (3, 4, 1)
     np.testing.assert_array_equal(b[..., 0], a)
+    # a non-contiguous map takes the general path and writes the same bytes
+    wide = np.zeros((3, 8), np.float32)
+    wide[:, ::2] = a
+    data_io.save_map(str(tmp_path / "v.bin"), wide[:, ::2])
+    assert open(str(tmp_path / "v.bin"), "rb").read() == raw
     with pytest.raises(Exception):
         data_io.read_map(str(tmp_path / "x.png"))
 
@@ -170,6 +178,29 @@ def test_gather_single_process_is_identity():
     local = {5: torch.rand(2, 4, 4), 9: torch.rand(2, 4, 4)}
     out = pdist.gather_scan_maps(local, [5, 9], 4, 4, torch.device("cpu"))
     assert torch.equal(out[5], local[5]) and torch.equal(out[9], local[9])
+
+
+def test_uint8_images_are_the_float_images_times_255(tmp_path):
+    """MVSDataset.uint8_images (eval.py's upload format): the bytes whose float32 division by 255 IS read_image's output; files
+    that read_image would down-scale keep coming as float32."""
+    data = str(tmp_path / "data")
+    synth.write_scan(data, "s", n_views=3, H=48, W=64, n_src=2)
+    with open(os.path.join(data, "list.txt"), "w") as f:
+        f.write("s\n")
+    ds = MVSDataset(data, num_views=2, scan_list=os.path.join(data, "list.txt"))
+    ref = ds[0]
+    ds.uint8_images = True
+    got = ds[0]
+    for a, b in zip(ref["images"], got["images"]):
+        assert b.dtype == np.uint8 and b.shape == a.shape
+        np.testing.assert_array_equal(b.astype(np.float32) / 255.0, a)
+    np.testing.assert_array_equal(ref["intrinsics"], got["intrinsics"])
+    small = MVSDataset(data, num_views=2, max_dim=32, scan_list=os.path.join(data, "list.txt"))
+    small.uint8_images = True
+    assert small[0]["images"][0].dtype == np.float32 and small[0]["images"][0].shape == (3, 24, 32)
+    from patchmatchnet_amd.mvs import MVSViewDataset
+    v = MVSViewDataset(ds, "s", "", [0, 1])[1]
+    assert v["image"].dtype == np.uint8 and v["view"] == 1
 
 
 def test_ply_writer_layout(tmp_path):
