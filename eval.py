@@ -28,6 +28,7 @@ from torch.utils.data import DataLoader
 import patchmatchnet_amd as P
 from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
+from patchmatchnet_amd.graph import GraphedForward
 from patchmatchnet_amd.data_io import image_shape, read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
 from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
 
@@ -200,6 +201,10 @@ def save_depth(args, rank, world, device):
     1600x1200 view, stays on the device, channels-last); then the samples are run from their cameras alone.  Same maps, bit for
     bit, as the plain path (tests/test_eval_gpu.py)."""
     model = load_model(args, device)
+    # one HIP-graph replay per sample instead of ~55 Python-issued launches: the launch thread is what the uploads and the
+    # writer threads compete with (patchmatchnet_amd/graph.py; same maps bit for bit, tests/test_eval_gpu.py)
+    forward = GraphedForward(model) if args.hip_graph else \
+        (lambda *a, **kw: model(*a, **kw)[:2])
     dataset = MVSDataset(data_path=args.input_folder, num_views=args.num_views, max_dim=args.image_max_dim,
                          scan_list=args.scan_list, num_light_idx=args.num_light_idx).shard(rank, world)
     dataset.uint8_images = True  # 4x fewer PCIe bytes per image; DevicePrefetcher restores the float32 image on the device
@@ -218,8 +223,8 @@ def save_depth(args, rank, world, device):
                 for sample in DevicePrefetcher(loader, device):
                     start = time.time()
                     _seed_sample(args, dataset, sample)
-                    depth, confidence, _ = model(list(sample["images"]), sample["intrinsics"], sample["extrinsics"],
-                                                 sample["depth_min"], sample["depth_max"])
+                    depth, confidence = forward(list(sample["images"]), sample["intrinsics"], sample["extrinsics"],
+                                                sample["depth_min"], sample["depth_max"])
                     _write_maps(args, sample, depth, confidence, produced, writer)
                     done += len(sample["filename"])
                     print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
@@ -247,9 +252,9 @@ def save_depth(args, rank, world, device):
                 ids = [int(v) for v in sample["view_ids"][0]]
                 ref_img = images[ids[0]]
                 _seed_sample(args, dataset, sample)
-                depth, confidence, _ = model([ref_img] * len(ids), sample["intrinsics"].to(device),
-                                             sample["extrinsics"].to(device), sample["depth_min"].to(device),
-                                             sample["depth_max"].to(device), features=[pyramids[v] for v in ids])
+                depth, confidence = forward([ref_img] * len(ids), sample["intrinsics"].to(device),
+                                            sample["extrinsics"].to(device), sample["depth_min"].to(device),
+                                            sample["depth_max"].to(device), features=[pyramids[v] for v in ids])
                 _write_maps(args, sample, depth, confidence, produced, writer)
                 done += 1
                 print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
@@ -376,6 +381,8 @@ def build_parser():
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
                         "(-1 = one RNG stream per process, like the reference)")
     p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
+    p.add_argument("--hip_graph", type=int, default=1,
+                   help="1: replay the forward as a HIP graph (one launch per sample); 0: issue every kernel from Python")
     p.add_argument("--feature_cache", type=int, default=64,
                    help="> 0: decode and encode every view of a scan ONCE per rank and keep its FeatureNet pyramid on the device "
                         "(0 = re-decode and re-encode per sample like the reference; needs --batch_size 1)")

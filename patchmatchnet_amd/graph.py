@@ -1,0 +1,98 @@
+"""HIP-graph replay of PatchmatchNet.forward.
+
+One forward is ~55 kernel launches issued from Python (~3.5 ms of interpreter time at 1600x1200, N=5 -- as long as the kernels
+themselves run).  Forward-only that cost hides behind the GPU; in a pipeline whose launch thread also stages uploads and hands
+finished maps to writer threads it is the bottleneck (scripts/pipeline_bench.py).  ``GraphedForward`` captures the forward once
+per input signature into a HIP graph (torch.cuda.CUDAGraph over the ctypes launches: every entry point of libpmn_hip.so only
+enqueues on the current stream, so the library is capturable as is) and replays it: one launch per sample, the interpreter is
+free for the I/O around it.
+
+Same results as the eager call, bit for bit, including the stage-3 random draw: the draw is a captured Philox kernel whose
+seed / offset are re-read from the generator at every replay, so ``torch.manual_seed(s)`` followed by a replay draws what the
+eager forward draws after ``torch.manual_seed(s)`` (tests/test_eval_gpu.py).
+
+Reference: models/net.py:176-301 (PatchmatchNet.forward) is what one graph holds; eval.py:56-64 is the loop that replays it.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import PmnError
+
+
+class GraphedForward:
+    """``GraphedForward(model)(images, intrinsics, extrinsics, depth_min, depth_max, features=None)`` -> (depth, confidence).
+
+    The returned tensors are the graph's static outputs: consume (copy) them before the next call with the same signature
+    overwrites them.  Inputs whose sizes PatchmatchNet.forward would adjust (height / width not multiples of 8, reference
+    net.py:304-318) run eagerly -- that path resizes the images and rewrites the caller's intrinsics in place."""
+
+    def __init__(self, model, max_graphs: int = 8) -> None:
+        self.model, self.max_graphs = model, max_graphs
+        self.cache: Dict[Tuple, Tuple] = {}
+        self.replays = 0
+
+    @staticmethod
+    def _signature(images: Sequence[torch.Tensor], intrinsics: torch.Tensor, features) -> Tuple:
+        feat = None if features is None else tuple(tuple((s, tuple(t.shape)) for s, t in sorted(f.items())) for f in features)
+        return tuple(tuple(i.shape) for i in images), tuple(intrinsics.shape), feat
+
+    def _capture(self, images, intrinsics, extrinsics, depth_min, depth_max, features):
+        dev = intrinsics.device
+        static = dict(images=[torch.empty_like(i) for i in images], intrinsics=torch.empty_like(intrinsics),
+                      extrinsics=torch.empty_like(extrinsics), depth_min=torch.empty_like(depth_min),
+                      depth_max=torch.empty_like(depth_max),
+                      features=None if features is None else [{s: torch.empty_like(t) for s, t in f.items()} for f in features])
+        self._fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features)
+
+        def run():
+            return self.model(list(static["images"]), static["intrinsics"], static["extrinsics"], static["depth_min"],
+                              static["depth_max"], features=static["features"])
+
+        rng = torch.cuda.get_rng_state(dev)  # warm-up and capture must not advance the caller's random stream
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # one eager pass off the capture: lazy kernel attributes, weight packing, allocator warm-up
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            depth, confidence, _ = run()
+        torch.cuda.set_rng_state(rng, dev)
+        return graph, static, (depth, confidence)
+
+    @staticmethod
+    def _fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
+        for dst, src in zip(static["images"], images):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        static["intrinsics"].copy_(intrinsics, non_blocking=True)
+        static["extrinsics"].copy_(extrinsics, non_blocking=True)
+        static["depth_min"].copy_(depth_min, non_blocking=True)
+        static["depth_max"].copy_(depth_max, non_blocking=True)
+        if features is not None:
+            for dst, src in zip(static["features"], features):
+                for s, t in src.items():
+                    dst[s].copy_(t, non_blocking=True)
+
+    def __call__(self, images: List[torch.Tensor], intrinsics: torch.Tensor, extrinsics: torch.Tensor,
+                 depth_min: torch.Tensor, depth_max: torch.Tensor, features: Optional[List[Dict[int, torch.Tensor]]] = None):
+        if not intrinsics.is_cuda:
+            raise PmnError("GraphedForward replays HIP graphs: the inputs must be on a ROCm device")
+        h, w = images[0].shape[-2:]
+        if h % 8 or w % 8 or any(tuple(i.shape) != tuple(images[0].shape) for i in images):
+            depth, confidence, _ = self.model(images, intrinsics, extrinsics, depth_min, depth_max, features=features)
+            return depth, confidence
+        key = self._signature(images, intrinsics, features)
+        entry = self.cache.get(key)
+        if entry is None:
+            if len(self.cache) >= self.max_graphs:  # a new signature per call would pin memory without bound
+                self.cache.pop(next(iter(self.cache)))
+            entry = self.cache[key] = self._capture(images, intrinsics, extrinsics, depth_min, depth_max, features)
+        graph, static, out = entry
+        self._fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features)
+        graph.replay()
+        self.replays += 1
+        return out

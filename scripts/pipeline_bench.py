@@ -20,6 +20,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 import eval as pm_eval  # noqa: E402
 import patchmatchnet_amd as P  # noqa: E402
+from patchmatchnet_amd.graph import GraphedForward  # noqa: E402
 
 
 def main():
@@ -45,6 +46,12 @@ def main():
     def forward(s):
         return model(list(s["images"]), s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
 
+    graphed = GraphedForward(model)
+
+    def forward_graph(s):
+        d, c = graphed(list(s["images"]), s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
+        return d, c, None
+
     with torch.no_grad():
         for i in range(30):
             forward(dev_samples[i % args.distinct])
@@ -58,9 +65,10 @@ def main():
         out = {}
         runs = [("h2d+forward", 1, args.outdirs[0])] + [("h2d+forward+d2h+write", t, o) for o in args.outdirs
                                                         for t in args.writer_threads]
-        runs = [(m, t, o, src) for src in ("float32", "uint8") for m, t, o in runs]
-        for mode, threads, parent, src in runs:
-            mode = src + " " + mode
+        runs = [(m, t, o, src, g) for g in ("eager", "graph") for src in ("float32", "uint8") for m, t, o in runs]
+        for mode, threads, parent, src, how in runs:
+            mode = how + " " + src + " " + mode
+            fwd_fn = forward if how == "eager" else forward_graph
             with tempfile.TemporaryDirectory(dir=parent) as tmp:
                 writer = pm_eval.MapWriter(dev, args.format, workers=threads)
                 pool = host if src == "float32" else host_u8
@@ -71,7 +79,7 @@ def main():
                         torch.cuda.synchronize()
                         writer.drain()
                         t = time.time()
-                    depth, conf, _ = forward(s)
+                    depth, conf, _ = fwd_fn(s)
                     if mode.endswith("write"):
                         writer.submit(torch.stack((depth[0, 0], conf[0]), 0), os.path.join(tmp, "depth_est", "%08d%s" % (n, args.format)),
                                       os.path.join(tmp, "confidence", "%08d%s" % (n, args.format)))
@@ -82,8 +90,8 @@ def main():
                 print("%s, %d writer threads, files under %s: %.1f samples/s" % (mode, threads, parent, args.samples / (time.time() - t)),
                       flush=True)
     res = {"forward_only_per_s": round(fwd, 1), **{k + "_per_s": round(v, 1) for k, v in out.items()},
-           "ratio_full_pipeline_float32_upload": round(out["float32 h2d+forward+d2h+write"] / fwd, 3),
-           "ratio_full_pipeline_uint8_upload": round(out["uint8 h2d+forward+d2h+write"] / fwd, 3), "samples": args.samples,
+           "ratio_full_pipeline_eager_float32_upload": round(out["eager float32 h2d+forward+d2h+write"] / fwd, 3),
+           "ratio_full_pipeline_graph_uint8_upload": round(out["graph uint8 h2d+forward+d2h+write"] / fwd, 3), "samples": args.samples,
            "h2d_MB_per_sample": {"float32": round((N + 1) * 3 * H * W * 4 / 1e6, 1), "uint8": round((N + 1) * 3 * H * W / 1e6, 1)},
            "d2h_MB_per_sample": round(2 * H * W * 4 / 1e6, 1),
            "format": args.format}

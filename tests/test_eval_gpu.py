@@ -78,6 +78,38 @@ def test_uint8_upload_restores_numpy_division():
     np.testing.assert_array_equal(got, np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0)
 
 
+def test_hip_graph_replay_writes_the_same_bytes(tmp_path):
+    """eval.py --hip_graph 1 (default: one HIP-graph replay per sample, patchmatchnet_amd/graph.py) against --hip_graph 0 (every
+    kernel launched from Python): every map byte-identical, in the plain path and in the encode-once path, with the stage-3
+    random draw seeded per sample (the captured Philox kernel must draw what the eager forward draws)."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    sys.path.insert(0, ROOT)
+    import eval as pm_eval
+    from patchmatchnet_amd import data_io
+    data = str(tmp_path / "data")
+    synth.write_scan(data, "scanG", n_views=5, H=96, W=128, n_src=2)
+    with open(os.path.join(data, "list.txt"), "w") as f:
+        f.write("scanG\n")
+    ckpt = os.path.join(GU.GOLDEN_DIR, "params_000007.npz")
+    outs = {}
+    for graph in ("0", "1"):
+        for cache in ("0", "64"):
+            out = str(tmp_path / ("out_g" + graph + "_c" + cache))
+            pm_eval.main(["--input_folder", data, "--output_folder", out, "--checkpoint_path", ckpt, "--scan_list",
+                          os.path.join(data, "list.txt"), "--num_views", "2", "--output_type", "depth", "--num_workers", "0",
+                          "--sample_seed", "5", "--hip_graph", graph, "--feature_cache", cache])
+            outs[(graph, cache)] = out
+    base = outs[("0", "0")]
+    for key, out in outs.items():
+        for v in range(5):
+            for kind in ("depth_est", "confidence"):
+                a = open(os.path.join(base, "scanG", kind, "{:0>8}.pfm".format(v)), "rb").read()
+                b = open(os.path.join(out, "scanG", kind, "{:0>8}.pfm".format(v)), "rb").read()
+                assert a == b, (key, kind, v)
+    d = data_io.read_map(os.path.join(base, "scanG", "depth_est", "00000003.pfm"))
+    assert np.isfinite(d).all() and d.min() > 300
+
+
 def _run_eval(cmd_args, env_extra, cwd):
     import subprocess
     env = dict(os.environ)
