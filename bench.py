@@ -11,9 +11,17 @@ Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU
 with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
 confidence maps closes the timed region, as the per-scan gather before fusion does in eval.
 
-Extra objects on the line: ``roofline`` for the dominant kernel (pmn_warp_correlate; HIP events on the launch stream
-inside the timed region; algorithmic bytes per SURVEY.md 8(d)) and, at N=1, ``cpu_baseline`` = the CPU oracle
-(oracle/, the checker -- never the thing shipped) timed on the host cores over one full-size hot-path pass.
+Timed region (``value``): by default every GPU keeps TWO independent samples in flight, each on its own HIP stream and each
+forward issued as ONE HIP-graph replay (--in-flight S, patchmatchnet_amd/graph.py): the gathers sit on the vector-memory pipe,
+the convolutions on the matrix cores, the stem / aggregation on the VALU, so two forwards sharing the CUs finish sooner than
+back to back (+14 % depth-maps/s), and the graph removes the ~3.5 ms of Python launch work per forward from the critical path.
+``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
+(``single_stream_eager`` = one sample's latency).
+
+Extra objects on the line: ``roofline`` for the dominant kernel (pmn_warp_correlate; HIP events on the launch stream around
+its launches in an eager single-stream pass of the same run -- launches inside a replayed graph cannot be bracketed and
+overlapped kernels have no duration of their own; algorithmic bytes per SURVEY.md 8(d)) and, at N=1, ``cpu_baseline`` = the
+CPU oracle (oracle/, the checker -- never the thing shipped) timed on the host cores over one full-size hot-path pass.
 """
 import argparse
 import json
@@ -126,6 +134,12 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--views", type=int, default=5, help="number of SOURCE views (reference eval.py --num_views)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent samples in flight per GPU: one HIP stream + one HIP-graph replay slot each (1 = one stream)")
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every kernel from Python on one stream (the round-1 mode) instead of replaying HIP graphs")
+    ap.add_argument("--roofline-steps", type=int, default=24,
+                    help="eager single-stream steps after the timed region that carry the HIP events of the roofline figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,34 +170,81 @@ def main():
         return model([im for im in s["images"]], s["intrinsics"].clone(), s["extrinsics"], s["depth_min"],
                      s["depth_max"])
 
-    EV = 4
-    sampled = len(range(0, args.steps, EV))
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-        ops.enable_kernel_timing()
-        t0 = time.perf_counter()
-        outs = None
-        for i in range(args.steps):
-            # HIP events around the pmn_warp_correlate launches of every EV-th step only: an event pair costs ~10 us of stream
-            # time on ROCm (a blit per record), 2.5 % of a step when every launch is bracketed
-            ops.pause_kernel_timing(i % EV != 0)
-            depth, conf, _ = step(i)
-            outs = (depth, conf)
+    def close_region(outs):
+        """The per-scan gather of the final maps before fusion: the only collective of the path (RCCL over xGMI)."""
         if world > 1:
-            # per-scan gather of the final maps before fusion: the only collective of the path (RCCL over xGMI)
             mine = torch.stack([outs[0][0, 0], outs[1][0]], 0).contiguous()
             gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=device)
             dist.all_gather_into_tensor(gathered, mine)
         barrier()
-        elapsed = time.perf_counter() - t0
+
+    # ---- timed region: `value` ------------------------------------------------------------------------------------------
+    # Default: S samples in flight, each on its own HIP stream, each forward one HIP-graph replay (patchmatchnet_amd/graph.py).
+    # The kernels of a forward are bound by different units (vector-memory pipe for the gathers, matrix cores for the
+    # convolutions, VALU for the stem / aggregation), so two forwards sharing the CUs finish sooner than one after the other;
+    # the graph takes the ~3.5 ms of Python launch work per forward off the critical path.  Every step runs the whole forward on
+    # its own inputs (copied into the slot's static buffers inside the timed region).
+    S = 1 if args.eager else max(args.in_flight, 1)
+    main_stream = torch.cuda.current_stream(device)
+    with torch.no_grad():
+        if args.eager:
+            for i in range(args.warmup):
+                step(i)
+            barrier()
+            t0 = time.perf_counter()
+            outs = None
+            for i in range(args.steps):
+                depth, conf, _ = step(i)
+                outs = (depth, conf)
+            close_region(outs)
+            elapsed = time.perf_counter() - t0
+        else:
+            from patchmatchnet_amd.graph import GraphedForward
+            streams = [torch.cuda.Stream(device) for _ in range(S)]
+            slots = [GraphedForward(model) for _ in range(S)]
+
+            def replay(i):
+                k, s = i % S, samples[i % len(samples)]
+                with torch.cuda.stream(streams[k]):
+                    return slots[k]([im for im in s["images"]], s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
+
+            for st in streams:
+                st.wait_stream(main_stream)
+            for i in range(max(args.warmup, S)):  # the first call of a slot captures its graph
+                replay(i)
+            barrier()
+            t0 = time.perf_counter()
+            outs = None
+            for i in range(args.steps):
+                outs = replay(i)
+            for st in streams:
+                main_stream.wait_stream(st)
+            close_region(outs)
+            elapsed = time.perf_counter() - t0
+
+        # ---- roofline pass: HIP events around the pmn_warp_correlate launches ------------------------------------------------
+        # Launches inside a replayed graph cannot be bracketed by events, and kernels of two overlapped forwards do not have a
+        # duration of their own; the dominant kernel is therefore timed in R eager single-stream steps of the same process, on
+        # the launch stream, every EV-th step (an event pair costs ~10 us of stream time on ROCm -- a blit per record -- 2.5 % of
+        # a step when every launch is bracketed).  The wall clock of this pass is the single-stream eager rate.
+        EV = 4
+        R = max(args.roofline_steps, EV)
+        sampled = len(range(0, R, EV))
+        for i in range(3):
+            step(i)
+        barrier()
+        ops.enable_kernel_timing()
+        t1 = time.perf_counter()
+        for i in range(R):
+            ops.pause_kernel_timing(i % EV != 0)
+            step(i)
+        torch.cuda.synchronize()
+        eager_elapsed = time.perf_counter() - t1
     recs = ops.disable_kernel_timing()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -229,11 +290,18 @@ def main():
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
                                    f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
                        "distinct_samples": len(samples),
-                       "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence"},
+                       "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
+                       "in_flight": S, "launch": "python, one stream" if args.eager else
+                       f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU"},
+            "single_stream_eager": {"value": round(R / eager_elapsed, 2), "ms_per_step": round(eager_elapsed / R * 1e3, 4),
+                                    "steps": R, "note": "this rank, one sample at a time, kernels issued from Python (the "
+                                    "round-1 mode; = one sample's latency); the roofline events were recorded in this pass"},
             "roofline": {"bound": "hbm", "kernel": "gather_corr_kernel (pmn_warp_correlate)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_unit": traffic_note,
+                         "measured_in": "eager single-stream pass of the same run (see single_stream_eager): a replayed "
+                                        "graph's launches cannot be bracketed by events",
                          "launches": len(recs), "steps_with_events": sampled,
                          "kernel_ms_per_step": round(k_ms / sampled, 4), "alg_bytes_per_step": int(k_bytes / sampled),
                          "per_shape": {k: {"ms_avg": round(v[0] / v[2], 4),

@@ -201,10 +201,32 @@ def save_depth(args, rank, world, device):
     1600x1200 view, stays on the device, channels-last); then the samples are run from their cameras alone.  Same maps, bit for
     bit, as the plain path (tests/test_eval_gpu.py)."""
     model = load_model(args, device)
-    # one HIP-graph replay per sample instead of ~55 Python-issued launches: the launch thread is what the uploads and the
-    # writer threads compete with (patchmatchnet_amd/graph.py; same maps bit for bit, tests/test_eval_gpu.py)
-    forward = GraphedForward(model) if args.hip_graph else \
-        (lambda *a, **kw: model(*a, **kw)[:2])
+    # --hip_graph: one HIP-graph replay per sample instead of ~55 Python-issued launches -- the launch thread is what the
+    # uploads and the writer threads compete with; --in_flight S: S samples in flight, each on its own HIP stream with its own
+    # replay slot, so that the gathers of one sample (vector-memory pipe) share the CUs with the convolutions of the other
+    # (matrix cores).  Same maps bit for bit (patchmatchnet_amd/graph.py, tests/test_eval_gpu.py).
+    main_stream = torch.cuda.current_stream(device)
+    n_slots = max(args.in_flight, 1) if args.hip_graph else 1
+    streams = [torch.cuda.Stream(device) for _ in range(n_slots)] if args.hip_graph else [main_stream]
+    if args.hip_graph:
+        slots = [GraphedForward(model) for _ in range(n_slots)]
+    else:
+        slots = [lambda *a, **kw: model(*a, **kw)[:2]]
+    turn = [0]
+
+    def run_sample(sample_tensors, *fargs, **fkw):
+        """The forward of the next sample on the next slot's stream (ordered after everything the main stream has queued, i.e.
+        the sample's upload); returns that stream for the caller's own work on the outputs."""
+        k = turn[0] % n_slots
+        turn[0] += 1
+        st = streams[k]
+        if st is not main_stream:
+            st.wait_stream(main_stream)
+            for t in sample_tensors:
+                t.record_stream(st)
+        with torch.cuda.stream(st):
+            return st, slots[k](*fargs, **fkw)
+
     dataset = MVSDataset(data_path=args.input_folder, num_views=args.num_views, max_dim=args.image_max_dim,
                          scan_list=args.scan_list, num_light_idx=args.num_light_idx).shard(rank, world)
     dataset.uint8_images = True  # 4x fewer PCIe bytes per image; DevicePrefetcher restores the float32 image on the device
@@ -223,9 +245,11 @@ def save_depth(args, rank, world, device):
                 for sample in DevicePrefetcher(loader, device):
                     start = time.time()
                     _seed_sample(args, dataset, sample)
-                    depth, confidence = forward(list(sample["images"]), sample["intrinsics"], sample["extrinsics"],
-                                                sample["depth_min"], sample["depth_max"])
-                    _write_maps(args, sample, depth, confidence, produced, writer)
+                    tensors = list(sample["images"]) + [sample[k] for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
+                    st, (depth, confidence) = run_sample(tensors, list(sample["images"]), sample["intrinsics"],
+                                                         sample["extrinsics"], sample["depth_min"], sample["depth_max"])
+                    with torch.cuda.stream(st):
+                        _write_maps(args, sample, depth, confidence, produced, writer)
                     done += len(sample["filename"])
                     print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
                 continue
@@ -252,13 +276,17 @@ def save_depth(args, rank, world, device):
                 ids = [int(v) for v in sample["view_ids"][0]]
                 ref_img = images[ids[0]]
                 _seed_sample(args, dataset, sample)
-                depth, confidence = forward([ref_img] * len(ids), sample["intrinsics"].to(device),
-                                            sample["extrinsics"].to(device), sample["depth_min"].to(device),
-                                            sample["depth_max"].to(device), features=[pyramids[v] for v in ids])
-                _write_maps(args, sample, depth, confidence, produced, writer)
+                cams = [sample[k].to(device) for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
+                st, (depth, confidence) = run_sample(cams, [ref_img] * len(ids), *cams, features=[pyramids[v] for v in ids])
+                with torch.cuda.stream(st):
+                    _write_maps(args, sample, depth, confidence, produced, writer)
                 done += 1
                 print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
             dataset.load_images = True
+            for st in streams:  # the next group's encode pass (main stream) frees the pyramids the slots are still reading
+                main_stream.wait_stream(st)
+    for st in streams:
+        main_stream.wait_stream(st)
     writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
     return produced
 
@@ -381,6 +409,8 @@ def build_parser():
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
                         "(-1 = one RNG stream per process, like the reference)")
     p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
+    p.add_argument("--in_flight", type=int, default=2,
+                   help="samples in flight per GPU (HIP streams, one graph-replay slot each); needs --hip_graph 1")
     p.add_argument("--hip_graph", type=int, default=1,
                    help="1: replay the forward as a HIP graph (one launch per sample); 0: issue every kernel from Python")
     p.add_argument("--feature_cache", type=int, default=64,

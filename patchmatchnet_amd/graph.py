@@ -58,7 +58,9 @@ class GraphedForward:
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: eval.py's writer threads, the DataLoader's pin-memory thread and RCCL's watchdog keep calling into the
+        # runtime (event waits, pinned allocations) while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             depth, confidence, _ = run()
         torch.cuda.set_rng_state(rng, dev)
         return graph, static, (depth, confidence)

@@ -52,6 +52,11 @@ def main():
         d, c = graphed(list(s["images"]), s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
         return d, c, None
 
+    # two samples in flight, as eval.py --in_flight 2: a HIP stream + a replay slot each
+    main_stream = torch.cuda.current_stream(dev)
+    streams2 = [torch.cuda.Stream(dev) for _ in range(2)]
+    slots2 = [GraphedForward(model) for _ in range(2)]
+
     with torch.no_grad():
         for i in range(30):
             forward(dev_samples[i % args.distinct])
@@ -65,7 +70,7 @@ def main():
         out = {}
         runs = [("h2d+forward", 1, args.outdirs[0])] + [("h2d+forward+d2h+write", t, o) for o in args.outdirs
                                                         for t in args.writer_threads]
-        runs = [(m, t, o, src, g) for g in ("eager", "graph") for src in ("float32", "uint8") for m, t, o in runs]
+        runs = [(m, t, o, src, g) for g in ("eager", "graph", "graphx2") for src in ("float32", "uint8") for m, t, o in runs]
         for mode, threads, parent, src, how in runs:
             mode = how + " " + src + " " + mode
             fwd_fn = forward if how == "eager" else forward_graph
@@ -79,10 +84,22 @@ def main():
                         torch.cuda.synchronize()
                         writer.drain()
                         t = time.time()
-                    depth, conf, _ = fwd_fn(s)
-                    if mode.endswith("write"):
-                        writer.submit(torch.stack((depth[0, 0], conf[0]), 0), os.path.join(tmp, "depth_est", "%08d%s" % (n, args.format)),
-                                      os.path.join(tmp, "confidence", "%08d%s" % (n, args.format)))
+                    st = main_stream
+                    if how == "graphx2":
+                        st = streams2[n % 2]
+                        st.wait_stream(main_stream)
+                        for tt in list(s["images"]) + [s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"]]:
+                            tt.record_stream(st)
+                    with torch.cuda.stream(st):
+                        if how == "graphx2":
+                            depth, conf = slots2[n % 2](list(s["images"]), s["intrinsics"], s["extrinsics"], s["depth_min"],
+                                                        s["depth_max"])
+                        else:
+                            depth, conf, _ = fwd_fn(s)
+                        if mode.endswith("write"):
+                            writer.submit(torch.stack((depth[0, 0], conf[0]), 0),
+                                          os.path.join(tmp, "depth_est", "%08d%s" % (n, args.format)),
+                                          os.path.join(tmp, "confidence", "%08d%s" % (n, args.format)))
                     n += 1
                 torch.cuda.synchronize()
                 writer.close()
@@ -91,7 +108,9 @@ def main():
                       flush=True)
     res = {"forward_only_per_s": round(fwd, 1), **{k + "_per_s": round(v, 1) for k, v in out.items()},
            "ratio_full_pipeline_eager_float32_upload": round(out["eager float32 h2d+forward+d2h+write"] / fwd, 3),
-           "ratio_full_pipeline_graph_uint8_upload": round(out["graph uint8 h2d+forward+d2h+write"] / fwd, 3), "samples": args.samples,
+           "ratio_full_pipeline_graph_uint8_upload": round(out["graph uint8 h2d+forward+d2h+write"] / fwd, 3),
+           "ratio_full_pipeline_graphx2_uint8_upload": round(out["graphx2 uint8 h2d+forward+d2h+write"] / fwd, 3),
+           "samples": args.samples,
            "h2d_MB_per_sample": {"float32": round((N + 1) * 3 * H * W * 4 / 1e6, 1), "uint8": round((N + 1) * 3 * H * W / 1e6, 1)},
            "d2h_MB_per_sample": round(2 * H * W * 4 / 1e6, 1),
            "format": args.format}
