@@ -3,7 +3,10 @@
 mkdir -p gpurun_out/prof gpurun_out/prof_summary
 export TMPDIR=/tmp
 STEPS=${1:-10}
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
+MODE=--eager   # kernels one at a time: their own durations; "default" as 2nd argument = the default command (two samples in flight)
+[ "$2" = "default" ] && MODE=
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof $GRAFT_REPO_ROOT/gpurun_out/prof_summary; mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof $GRAFT_REPO_ROOT/gpurun_out/prof_summary
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $MODE > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do cp $f gpurun_out/prof_summary/; done

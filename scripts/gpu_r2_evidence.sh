@@ -13,10 +13,12 @@ python bench.py > $E/bench.json 2> $E/bench.err
 tail -1 $E/bench.json
 bash scripts/gpu_profile.sh 20 > $E/profile.txt 2>&1
 cp gpurun_out/prof_summary/*kernel_stats.csv $E/bench_kernel_stats.csv
+bash scripts/gpu_profile.sh 20 default > $E/profile_default.txt 2>&1
+cp gpurun_out/prof_summary/*kernel_stats.csv $E/bench_default_kernel_stats.csv
 bash scripts/gpu_pmc_bench.sh > $E/pmc_bench.txt 2>&1
 cp gpurun_out/pmc_bench/summary.txt $E/pmc_all_kernels.txt
-EVAL_WORKERS=4 timeout 600 python scripts/eval_bench.py 16 > $E/eval_bench.log 2>&1
-grep RESULT $E/eval_bench.log
+timeout 400 python scripts/pipeline_bench.py --samples 128 --writer_threads 3 --outdirs /dev/shm > $E/pipeline_bench.log 2>&1
+grep PIPELINE $E/pipeline_bench.log | cut -c1-300
 timeout 60 scripts/microbench/ta_mask > $E/ta_mask.txt 2>&1
 rm -rf gpurun_out/pmc_win/p*/*/*.db gpurun_out/pmc_bench/p*/*/*.db 2>/dev/null
 du -sh gpurun_out | tail -1
