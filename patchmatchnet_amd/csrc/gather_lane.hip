@@ -160,34 +160,23 @@ __device__ __forceinline__ LaneWin lane_make_window(int lo_x, int hi_x, int lo_y
     return g;
 }
 
-// Stage the window of one source map's 16-channel slice into the wave's LDS region (texel-major, 64 B per texel): a
-// wave-instruction moves 16 texels of one window row; NB loads are in flight before the first ds_write.
-template <int C, int NB>
-__device__ __forceinline__ void lane_stage_window(pmn_lds_char* win, pmn_glb_char* src_slice, const LaneWin& g, int ws, int lane) {
-    const int nseg = (g.bw + 15) >> 4;
-    const int total = g.bh * nseg;
+// Stage the window of one source map's 16-channel slice into the wave's LDS region (texel-major, 64 B per texel) by LDS-DMA
+// (global_load_lds_dwordx4): a wave-instruction moves 16 texels of one window row (lane = texel * 4 + channel quad) straight
+// from the L1 return path into LDS at base + lane * 16 -- no staging registers, no ds_write, no VALU beyond the source address
+// (the register-staged form of gather_win.hip measured 211 / 250 / 231 us on the s3-it2 / s2 / s1 launches, this one 186 / 224 /
+// 221; streaming: 170 / 172 / 183).  Lanes past the end of a row are masked off (their destination would be the next row's first texels).
+// Nothing waits here: the caller waits for vmcnt(0) before the first ds_read of the window.
+template <int C>
+__device__ __forceinline__ void lane_stage_window_dma(pmn_lds_char* win, pmn_glb_char* src_slice, const LaneWin& g, int ws, int lane) {
     const int tcol = lane >> 2, quad = lane & 3;
-    int r = 0, c0 = 0;
-    for (int s0 = 0; s0 < total; s0 += NB) {
-        pmn_f4 buf[NB];
-        int rr = r, cc = c0;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {  // unconditional loads at clamped (always legal) positions; the stores are masked
-            const int col = min(cc + tcol, g.bw - 1), row = min(rr, g.bh - 1);
-            const unsigned go = ((unsigned)((g.by0 + row) * ws + g.bx0 + col) * (unsigned)(C * 4)) + quad * 16u;
-            buf[k] = PMN_GLB_F4(src_slice + go);
-            cc += 16;
-            if (cc >= g.bw) { cc = 0; ++rr; }
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(buf[k]));  // keeps hipcc from sinking each load into its store's branch
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int col = c0 + tcol;
-            if (s0 + k < total && col < g.bw) PMN_LDS_F4(win + ((((unsigned)(r * g.bw + col)) << 6) + quad * 16u)) = buf[k];
-            c0 += 16;
-            if (c0 >= g.bw) { c0 = 0; ++r; }
+    for (int r = 0; r < g.bh; ++r) {
+        const unsigned grow = (unsigned)((g.by0 + r) * ws + g.bx0);
+        for (int c0 = 0; c0 < g.bw; c0 += 16) {
+            if (c0 + tcol < g.bw) {
+                const unsigned go = (grow + (unsigned)(c0 + tcol)) * (unsigned)(C * 4) + quad * 16u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_slice + go),
+                                                 (__attribute__((address_space(3))) void*)(win + (((unsigned)(r * g.bw + c0)) << 6)), 16, 0, 0);
+            }
         }
     }
 }
@@ -414,7 +403,10 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
                 refq[j] = pmn_f4{0.f, 0.f, 0.f, 0.f};
                 if (ok) refq[j] = PMN_GLB_F4(refp + (sl * 64 + ofs[j]));
             }
-            if (!(dbg & 1)) lane_stage_window<C, 8>(win, src_slice, g, ws, lane);
+            if (!(dbg & 1)) {
+                lane_stage_window_dma<C>(win, src_slice, g, ws, lane);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the window has landed
+            }
 #pragma unroll
             for (int s2 = 0; s2 < DCH / 2; ++s2) {
                 float simp[2][GPS];
