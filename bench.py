@@ -149,11 +149,26 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    if os.environ.get("PMN_DIST_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()  # several ranks on one GPU (control-flow test only)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # nccl (= RCCL over xGMI) is the product's backend; PMN_DIST_BACKEND=gloo exists so that the multi-rank control flow can be
+        # exercised with several ranks on ONE GPU (collectives then stage through the host)
+        backend = os.environ.get("PMN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    on_host = world > 1 and dist.get_backend() != "nccl"
+
+    def reduce_scalar(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_host else device)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return float(t.item())
 
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops
@@ -179,7 +194,9 @@ def main():
         """The per-scan gather of the final maps before fusion: the only collective of the path (RCCL over xGMI)."""
         if world > 1:
             mine = torch.stack([outs[0][0, 0], outs[1][0]], 0).contiguous()
-            gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=device)
+            if on_host:
+                mine = mine.cpu()
+            gathered = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
             dist.all_gather_into_tensor(gathered, mine)
         barrier()
 
@@ -207,6 +224,8 @@ def main():
             return time.perf_counter() - t0
 
         def timed_in_flight():
+            """Returns the elapsed time, or None when some rank could not capture its graphs (decided collectively before the
+            timed region, so that every rank then takes the same path)."""
             from patchmatchnet_amd.graph import GraphedForward
             streams = [torch.cuda.Stream(device) for _ in range(S)]
             slots = [GraphedForward(model) for _ in range(S)]
@@ -218,8 +237,15 @@ def main():
 
             for st in streams:
                 st.wait_stream(main_stream)
-            for i in range(max(args.warmup, S)):  # the first call of a slot captures its graph
-                replay(i)
+            err = ""
+            try:
+                for i in range(max(args.warmup, S)):  # the first call of a slot captures its graph
+                    replay(i)
+                torch.cuda.synchronize()
+            except RuntimeError as e:
+                err = str(e).split("\n")[0][:120] or "RuntimeError"
+            if reduce_scalar(0.0 if err else 1.0, dist.ReduceOp.MIN) < 1.0:
+                return None, err or "capture failed on another rank"
             barrier()
             t0 = time.perf_counter()
             outs = None
@@ -228,18 +254,15 @@ def main():
             for st in streams:
                 main_stream.wait_stream(st)
             close_region(outs)
-            return time.perf_counter() - t0
+            return time.perf_counter() - t0, ""
 
         if args.eager:
             elapsed = timed_eager()
         else:
-            try:
-                elapsed = timed_in_flight()
-            except RuntimeError as e:  # a runtime that cannot capture: same kernels, launched from Python, and the line says so
-                if world > 1:
-                    raise
+            elapsed, why = timed_in_flight()
+            if elapsed is None:  # a runtime that cannot capture: same kernels, launched from Python, and the line says so
                 torch.cuda.synchronize()
-                launch_note = "python, one stream (HIP-graph capture failed: %s)" % str(e).split("\n")[0][:120]
+                launch_note = "python, one stream (HIP-graph capture failed: %s)" % why
                 S = 1
                 elapsed = timed_eager()
 
@@ -263,10 +286,7 @@ def main():
         eager_elapsed = time.perf_counter() - t1
     recs = ops.disable_kernel_timing()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

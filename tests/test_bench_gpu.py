@@ -1,0 +1,61 @@
+"""GPU tests of the measurement contract: bench.py prints ONE JSON line with the agreed keys, in the default mode (two samples
+in flight, HIP-graph replay), in the eager mode, and with two ranks (control flow of the multi-GPU launch: the collective
+decision about graph capture, the closing all-gather, max over ranks) -- the two ranks share cuda:0 over gloo, which is what this
+box allows; on a multi-GPU node the same code runs over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--width", "640", "--height", "480", "--steps", "6", "--warmup", "2", "--samples", "3", "--roofline-steps", "4",
+         "--no-cpu-baseline"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "single_stream_eager"}
+
+
+def _line(out: str) -> dict:
+    lines = [ln for ln in out.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(line: dict, n_gpus: int) -> None:
+    assert KEYS <= set(line), sorted(KEYS - set(line))
+    assert line["n_gpus"] == n_gpus and line["steps"] == 6 and line["higher_is_better"] is True
+    assert line["value"] > 0 and abs(line["value"] - n_gpus * 1e3 / line["ms_per_step"]) < 1e-2 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["launches"] == 5 * r["steps_with_events"]  # five pmn_warp_correlate launches per depth map
+
+
+def test_bench_line_default_and_eager():
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    for extra in ([], ["--eager"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = _line(p.stdout)
+        _check(line, 1)
+        assert line["config"]["in_flight"] == (1 if extra else 2)
+        assert ("graph" in line["config"]["launch"]) == (not extra), line["config"]["launch"]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    port = str(29700 + os.getpid() % 1000)
+    env = dict(os.environ, PMN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=ROOT) for r in range(2)]
+    outs = [q.communicate(timeout=900) for q in procs]
+    for q, (so, se) in zip(procs, outs):
+        assert q.returncode == 0, se[-3000:]
+    line = _line(outs[0][0])
+    _check(line, 2)
+    assert "{" not in outs[1][0]  # only rank 0 prints
+    assert line["config"]["in_flight"] == 2 and line["scaling"] == "weak"
