@@ -11,10 +11,11 @@ Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU
 with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
 confidence maps closes the timed region, as the per-scan gather before fusion does in eval.
 
-Timed region (``value``): by default every GPU keeps TWO independent samples in flight, each on its own HIP stream and each
+Timed region (``value``): by default every GPU keeps THREE independent samples in flight, each on its own HIP stream and each
 forward issued as ONE HIP-graph replay (--in-flight S, patchmatchnet_amd/graph.py): the gathers sit on the vector-memory pipe,
-the convolutions on the matrix cores, the stem / aggregation on the VALU, so two forwards sharing the CUs finish sooner than
-back to back (+14 % depth-maps/s), and the graph removes the ~3.5 ms of Python launch work per forward from the critical path.
+the convolutions on the matrix cores, the stem / aggregation on the VALU, so forwards sharing the CUs finish sooner than
+back to back (same box: 276 one at a time, 304.6 with two in flight, 310.6 with three, 298.6 with four), and the graph removes
+the ~3.5 ms of Python launch work per forward from the critical path.
 ``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
 (``single_stream_eager`` = one sample's latency).
 
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--views", type=int, default=5, help="number of SOURCE views (reference eval.py --num_views)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="independent samples in flight per GPU: one HIP stream + one HIP-graph replay slot each (1 = one stream)")
     ap.add_argument("--eager", action="store_true",
                     help="issue every kernel from Python on one stream (the round-1 mode) instead of replaying HIP graphs")
@@ -201,7 +202,7 @@ def main():
         barrier()
 
     # ---- timed region: `value` ------------------------------------------------------------------------------------------
-    # Default: S samples in flight, each on its own HIP stream, each forward one HIP-graph replay (patchmatchnet_amd/graph.py).
+    # Default: S = 3 samples in flight, each on its own HIP stream, each forward one HIP-graph replay (patchmatchnet_amd/graph.py).
     # The kernels of a forward are bound by different units (vector-memory pipe for the gathers, matrix cores for the
     # convolutions, VALU for the stem / aggregation), so two forwards sharing the CUs finish sooner than one after the other;
     # the graph takes the ~3.5 ms of Python launch work per forward off the critical path.  Every step runs the whole forward on

@@ -1,4 +1,4 @@
-"""GPU tests of the measurement contract: bench.py prints ONE JSON line with the agreed keys, in the default mode (two samples
+"""GPU tests of the measurement contract: bench.py prints ONE JSON line with the agreed keys, in the default mode (three samples
 in flight, HIP-graph replay), in the eager mode, and with two ranks (control flow of the multi-GPU launch: the collective
 decision about graph capture, the closing all-gather, max over ranks) -- the two ranks share cuda:0 over gloo, which is what this
 box allows; on a multi-GPU node the same code runs over RCCL."""
@@ -41,7 +41,7 @@ def test_bench_line_default_and_eager():
         assert p.returncode == 0, p.stderr[-3000:]
         line = _line(p.stdout)
         _check(line, 1)
-        assert line["config"]["in_flight"] == (1 if extra else 2)
+        assert line["config"]["in_flight"] == (1 if extra else 3)
         assert ("graph" in line["config"]["launch"]) == (not extra), line["config"]["launch"]
 
 
@@ -58,4 +58,4 @@ def test_bench_two_ranks_on_one_gpu():
     line = _line(outs[0][0])
     _check(line, 2)
     assert "{" not in outs[1][0]  # only rank 0 prints
-    assert line["config"]["in_flight"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["in_flight"] == 3 and line["scaling"] == "weak"
