@@ -491,6 +491,32 @@ def test_batch_of_two_equals_two_single_samples():
             assert torch.equal(d1[0], d2[b]) and torch.equal(c1[0], c2[b])
 
 
+def test_config0_one_iteration_per_stage_against_oracle():
+    """BASELINE configs[0]'s shape and schedule (160x128, 2 source views, ONE PatchMatch iteration per stage) through the HIP
+    cascade, against the oracle on the same features and noise (the oracle itself is pinned to the reference at this size in
+    tests/test_oracle_vs_reference.py).  With one iteration at stage 1 the reference skips propagation there and regresses in
+    inverse depth (patchmatch.py:465, :482)."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    kw = dict(kw, patchmatch_iteration=[1, 1, 1])
+    model = _model(P, params, kw)
+    H, W = 128, 160
+    imgs, K, E, dmin, dmax = _rand_sample(3, H, W)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(21))
+    with torch.no_grad():
+        feats = model.extract_features(imgs)
+        depth, conf, dpm = model([i.clone() for i in imgs], K.clone(), E, dmin, dmax, noise=noise.to(DEV), features=feats)
+    feats_np = [{s: np.ascontiguousarray(n(f[s])) for s in (1, 2, 3)} for f in feats]
+    d1, score, out = O.cascade(params, feats_np, n(K), n(E), n(dmin), n(dmax), noise.numpy(), configs=_configs(kw))
+    for stage in (3, 2, 1):
+        assert len(dpm[stage]) == 1
+        assert GU.rel_err(n(dpm[stage][0]), out[stage][0]) < 1e-3, stage
+    assert GU.rel_err(n(dpm[1][0]), d1) < 1e-3
+    c, _ = O.confidence(score, (H, W))
+    assert float((np.abs(n(conf) - c) > 1e-3).mean()) < 5e-3
+    assert depth.shape == (1, 1, H, W) and bool(torch.isfinite(depth).all())
+
+
 def test_sizes_not_multiple_of_8_are_resized_like_the_reference():
     """adjust_image_dims (reference net.py:304-318): inputs are stretched to multiples of 8, intrinsics rescaled IN
     PLACE, outputs come back at the original size."""
