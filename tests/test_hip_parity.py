@@ -517,6 +517,28 @@ def test_config0_one_iteration_per_stage_against_oracle():
     assert depth.shape == (1, 1, H, W) and bool(torch.isfinite(depth).all())
 
 
+def test_single_source_view_and_argument_errors():
+    """Smallest problem the reference accepts (one source view) against the oracle, and the reference's own argument checks
+    (models/net.py:196-197: one intrinsic / extrinsic matrix per image)."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    H, W = 64, 96
+    imgs, K, E, dmin, dmax = _rand_sample(2, H, W)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        feats = model.extract_features(imgs)
+        depth, conf, dpm = model([i.clone() for i in imgs], K.clone(), E, dmin, dmax, noise=noise.to(DEV), features=feats)
+    feats_np = [{s: np.ascontiguousarray(n(f[s])) for s in (1, 2, 3)} for f in feats]
+    d1, _, out = O.cascade(params, feats_np, n(K), n(E), n(dmin), n(dmax), noise.numpy(), configs=_configs(kw))
+    assert GU.rel_err(n(dpm[3][0]), out[3][0]) < 1e-3 and GU.rel_err(n(dpm[1][-1]), d1) < 1e-3
+    assert conf.shape == (1, H, W) and bool(torch.isfinite(depth).all())
+    with pytest.raises(AssertionError, match="Different number of images and intrinsic matrices"):
+        model(imgs, K[:, :1], E, dmin, dmax)
+    with pytest.raises(AssertionError, match="Different number of images and extrinsic matrices"):
+        model(imgs, K, E[:, :1], dmin, dmax)
+
+
 def test_sizes_not_multiple_of_8_are_resized_like_the_reference():
     """adjust_image_dims (reference net.py:304-318): inputs are stretched to multiples of 8, intrinsics rescaled IN
     PLACE, outputs come back at the original size."""
