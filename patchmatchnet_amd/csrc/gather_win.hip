@@ -6,7 +6,7 @@
 // roofline).  Neighbouring pixels and consecutive hypotheses read almost the same source texels, so here every WAVE stages the
 // bounding box of its taps -- a "window" of the source map -- into its own slice of LDS once per (view, 8 hypotheses) and takes
 // the taps from there (ds_read_b128: 256 B/clk/CU, no tags, no address coalescer): 7-20 taps per staged texel on the cascade's
-// hypotheses (scripts/footprint_study.py).
+// hypotheses (tests/studies/footprint_study.py).
 //
 // Reference: models/module.py:130-181 (differentiable_warping), models/patchmatch.py:192-217 (group correlation, view
 // aggregation), :570 (SimilarityNet MLP), :695-702 (PixelwiseNet).

@@ -6,13 +6,13 @@ product), then for every Evaluation call (stage, iteration) and source view proj
 tile and reports the bounding box of the tap texels per chunk of DCH consecutive hypotheses: width/height percentiles,
 texel counts, and the tap re-use factor a tile-private LDS window would get (taps / window texels).
 
-    python scripts/footprint_study.py [--width 1600 --height 1200] [--tw 16 --th 4 --dch 8]
+    python tests/studies/footprint_study.py [--width 1600 --height 1200] [--tw 16 --th 4 --dch 8]
 """
 import argparse
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -6,7 +6,7 @@ that fall outside their window (global path), and the share of wave-steps (64 it
     python scripts/window_sim.py [--cap 192] [--th 4] [--dch 8]
 """
 import argparse, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "scripts")):
     if p not in sys.path:
         sys.path.insert(0, p)
