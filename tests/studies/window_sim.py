@@ -3,7 +3,7 @@
 FeatureNet + CPU oracle): per launch and view, the share of (tile, round) windows that had to be cut down, the share of items
 that fall outside their window (global path), and the share of wave-steps (64 items) with at least one such item.
 
-    python scripts/window_sim.py [--cap 192] [--th 4] [--dch 8]
+    python tests/studies/window_sim.py [--cap 192] [--th 4] [--dch 8]
 """
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
