@@ -109,7 +109,15 @@ class MapWriter:
                     free.put(buf)
             return stacked  # keeps the device tensor alive until its copy has been consumed
 
-        self.futures.append(self.pool.submit(write))
+        # finished writes are retired here (their result is the device tensor they kept alive; a failed one re-raises now)
+        pending = []
+        for f in self.futures:
+            if f.done():
+                f.result()
+            else:
+                pending.append(f)
+        pending.append(self.pool.submit(write))
+        self.futures = pending
 
     def drain(self) -> None:
         for f in self.futures:
