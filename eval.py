@@ -12,7 +12,8 @@ path); with several processes every scan's reference views are cut into contiguo
 nn.DataParallel), each scan's maps are all-gathered over RCCL, and every rank then fuses its own block of reference views with
 one HIP kernel launch per view (pmn_fuse_view) instead of numpy/cv2; rank 0 stitches the per-rank point lists into fused.ply.
 Disk and PCIe traffic is taken off the critical path: decoded images go through pinned memory on a copy stream one sample
-ahead, finished maps leave through pinned buffers on the same stream and are written by a pool of writer threads.
+ahead, finished maps leave through pinned buffers on a second copy stream and are written by a pool of writer threads; the
+forward itself is one HIP-graph replay per sample, with --in_flight samples overlapping on their own streams.
 """
 import argparse
 import concurrent.futures
