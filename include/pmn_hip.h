@@ -229,6 +229,8 @@ int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const 
  *          gather_corr.hip); bit 4 = the first windowed form (gather_win.hip) instead of the lane = item engine
  *          (gather_lane.hip); bits 2 / 3 = keep the streaming kernel for the PixelwiseNet / the known-weights launches;
  *          bit 1 = gather_win.hip without the per-lane channel-quad rotation (bank-conflict A/B);
+ *          bit 5 = the tile-window kernel (gather_tile.hip) for the known-weights launches;
+ *   key 10: bytes of one of its two window buffers (multiple of 1024, 16384..65536);
  *   key 4: bytes of LDS each wave of gather_lane.hip may use for its source-map window (multiple of 1024, 1024..36864);
  *   key 6: gather_lane.hip build, 3 (168 registers, 3 waves per SIMD) or 2 (256 registers);
  *   keys 0, 2: window bytes of gather_win.hip (known-weights / PixelwiseNet kernels); keys 3, 5: timing ablations of

@@ -193,4 +193,7 @@ int pmn_launch_gather_win(GatherArgs& a, int C, int G, bool pixelwise, hipStream
 // gather_lane.hip: lane = item, wave-autonomous implementation (the default family); same contract.
 int pmn_launch_gather_lane(GatherArgs& a, int C, int G, bool pixelwise, hipStream_t stream);
 int pmn_lane_set_tuning(int key, int value);
+// gather_tile.hip: tile-window implementation of MODE_VIEWS (one LDS window per workgroup tile and view); same contract.
+int pmn_launch_gather_tile(GatherArgs& a, int C, int G, hipStream_t stream);
+int pmn_tile_set_tuning(int key, int value);
 int pmn_gather_flags();  // pmn_set_tuning key 1

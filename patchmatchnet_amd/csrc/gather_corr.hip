@@ -664,6 +664,10 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     // keep the streaming kernel for the PixelwiseNet / the known-weights launches only.
     const int flags = pmn_gather_flags();
     const bool pixelwise = view_weights_in == nullptr;
+    if ((flags & 32) && !pixelwise) {  // bit 5: the tile-window kernel (gather_tile.hip) for the known-weights launches
+        const int rc = pmn_launch_gather_tile(a, C, G, (hipStream_t)stream);
+        if (rc != PMN_ERR_SHAPE) return rc;
+    }
     if ((flags & 1) && !(flags & (pixelwise ? 4 : 8))) {
         const int rc = (flags & 16) ? pmn_launch_gather_win(a, C, G, pixelwise, (hipStream_t)stream)
                                     : pmn_launch_gather_lane(a, C, G, pixelwise, (hipStream_t)stream);

@@ -605,6 +605,7 @@ int pmn_gather_flags() { return g_win_flags; }
 
 extern "C" int pmn_set_tuning(int key, int value) {
     if (key >= 4 && key <= 6) return pmn_lane_set_tuning(key, value);
+    if (key == 10) return pmn_tile_set_tuning(key, value);
     if (key == 0) {
         if (value < 1024 || value > 40 * 1024 || (value & 1023)) return PMN_ERR_ARG;
         g_win_cap_bytes = value;

@@ -36,10 +36,12 @@ def timed(fn, reps):
 
 
 def parse_config(name, ops):
-    """stream | win<KB>[p<KB>][n][@<ablation bits>] (first windowed form; n = no quad rotation) | lane<KB>[w<2|3>][@<bits>]
+    """stream | tile<KB> | win<KB>[p<KB>][n][@<ablation bits>] (first windowed form; n = no quad rotation) | lane<KB>[w<2|3>][@<bits>]
     e.g. win12, win16p6, win12n, win12@3, lane12, lane16w2, lane12@3"""
     if name == "stream":
         return dict(flags=0, cap=12288, cap_pix=8192, dbg=0, lane=False, wps=3)
+    if name.startswith("tile"):  # tile<KB>: the tile-window kernel (known-weights launches), window buffer of <KB> KB
+        return dict(flags=ops.FLAG_TILE, cap=12288, cap_pix=8192, dbg=0, lane=False, wps=3, tile_cap=int(name[4:] or 20) * 1024)
     if name.startswith("lane"):
         body = name[4:]
         dbg = 0
@@ -102,6 +104,8 @@ def main():
 
     def apply(cfg):
         ops.set_tuning(ops.TUNE_FLAGS, cfg["flags"])
+        if "tile_cap" in cfg:
+            ops.set_tuning(ops.TUNE_TILE_WINDOW_BYTES, cfg["tile_cap"])
         if cfg["lane"]:
             ops.set_tuning(ops.TUNE_LANE_WINDOW_BYTES, cfg["cap"])
             ops.set_tuning(ops.TUNE_LANE_ABLATE, cfg["dbg"])

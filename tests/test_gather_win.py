@@ -88,6 +88,8 @@ def _compare(ops, case, C, pixelwise, vw_shift=0, caps=(12288,), seed=0):
         # families: lane = item engine built for 3 / 2 waves per SIMD, first windowed form with / without quad rotation
         variants = [(ops.FLAG_WINDOWED, 3), (ops.FLAG_WINDOWED, 2), (ops.FLAG_WINDOWED | ops.FLAG_WIN_V1, 3),
                     (ops.FLAG_WINDOWED | ops.FLAG_WIN_V1 | ops.FLAG_NO_ROTATION, 3)]
+        if not pixelwise:  # the tile-window kernel (gather_tile.hip) covers the known-weights launches
+            variants.append((ops.FLAG_TILE, 3))
         for cap in caps:
             for flags, wps in variants:
                 ops.set_tuning(ops.TUNE_FLAGS, flags)
@@ -95,6 +97,7 @@ def _compare(ops, case, C, pixelwise, vw_shift=0, caps=(12288,), seed=0):
                 ops.set_tuning(ops.TUNE_WINDOW_BYTES_PIXELWISE, min(cap, 8192))
                 ops.set_tuning(ops.TUNE_LANE_WINDOW_BYTES, cap)
                 ops.set_tuning(ops.TUNE_LANE_WAVES_PER_SIMD, wps)
+                ops.set_tuning(ops.TUNE_TILE_WINDOW_BYTES, max(16384, cap))  # 16 KB: small enough for stragglers on the tests' data
                 got = _run(ops, case, C, pixelwise, sim_mlp, pix_mlp, vw_shift)
                 for i, (a, b) in enumerate(zip(want, got)):
                     assert torch.isfinite(a.float()).all()
@@ -111,6 +114,7 @@ def _compare(ops, case, C, pixelwise, vw_shift=0, caps=(12288,), seed=0):
         ops.set_tuning(ops.TUNE_WINDOW_BYTES_PIXELWISE, 8192)
         ops.set_tuning(ops.TUNE_LANE_WINDOW_BYTES, 12288)
         ops.set_tuning(ops.TUNE_LANE_WAVES_PER_SIMD, 3)
+        ops.set_tuning(ops.TUNE_TILE_WINDOW_BYTES, 20480)
 
 
 @pytest.mark.parametrize("C,D,h,w,N,B,hyp", [
