@@ -23,7 +23,6 @@ typedef float pmn_t4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char pmn_tlds;        // LDS (ds_read / ds_write, never flat)
 typedef const __attribute__((address_space(1))) char pmn_tglb;  // global (global_load, never flat)
 #define PMN_TLDS_F4(p) (*reinterpret_cast<__attribute__((address_space(3))) pmn_t4*>(p))
-#define PMN_TLDS_I2(p) (*reinterpret_cast<__attribute__((address_space(3))) int2*>(p))
 #define PMN_TLDS_F(p) (*reinterpret_cast<__attribute__((address_space(3))) float*>(p))
 #define PMN_TLDS_I(p) (*reinterpret_cast<__attribute__((address_space(3))) int*>(p))
 #define PMN_TGLB_F4(p) (*reinterpret_cast<const __attribute__((address_space(1))) pmn_t4*>(p))
@@ -107,7 +106,9 @@ __device__ __forceinline__ void tile_wait(TileItem& a, TileItem& b) {
 }
 
 // grid = (pixel tiles of 16x4, D / DT hypothesis chunks, batch); 256 threads = 4 waves = the 4 rows of the tile.
-template <int C, int G, int DT, bool EXACT>
+// (the hypothesis count of a chunk, nd, stays a run-time value on purpose: with a compile-time count hipcc merges the walk's steps
+// and spills)
+template <int C, int G, int DT>
 __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherArgs a, const int cap_bytes) {
     constexpr int NS = C / 16;     // channel slices
     constexpr int CG = C / G;      // channels per correlation group (4 or 8)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
     const int hw = h * w;
     const int b = blockIdx.z;
     const int d_base = blockIdx.y * DT;
-    const int nd = EXACT ? DT : min(DT, D - d_base);
+    const int nd = min(DT, D - d_base);
     const int ntx = (w + 15) >> 4;
     const int tile = pmn_xcd_tile(blockIdx.x, a.ntiles);
     const int ty = tile / ntx, tx = tile - ty * ntx;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
             off[d4 + 2] = __float_as_int(o4.z); off[d4 + 3] = __float_as_int(o4.w);
         }
 #pragma unroll
-        for (int d = 0; d < DT; ++d) any_stray |= off[d] < 0 && (EXACT || d < nd);
+        for (int d = 0; d < DT; ++d) any_stray |= off[d] < 0 && d < nd;
         Geom nxt = cur;
         if (v + 1 < N) nxt = prepare_view(v + 1, (v + 1) & 1);
         pmn_tglb* vbase = (pmn_tglb*)a.src + ((size_t)(v * a.B + b) * hs * ws) * (C * 4);
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
                     if (LPG == 2) s += pmn_pair_swap(s);
                     s = s * (1.0f / CG);
                     const float upd = mul_add_unfused(acc[sl][d0 + i], s, vw);
-                    const bool take = off[d0 + i] >= 0 && (EXACT || d0 + i < nd);
+                    const bool take = off[d0 + i] >= 0 && d0 + i < nd;
                     acc[sl][d0 + i] = take ? upd : acc[sl][d0 + i];
                 }
             }
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
                 const unsigned rb = (unsigned)ws * (unsigned)(C * 4);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    const bool mine = off[d] < 0 && (EXACT || d < nd);
+                    const bool mine = off[d] < 0 && d < nd;
                     if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
                         const pmn_t4 wq = PMN_TLDS_F4(rcur + ((d * TP + wk_pix) << 4));
                         const unsigned go = (unsigned)(mine ? -off[d] - 1 : 0) * (unsigned)(C * 4);
@@ -461,8 +462,7 @@ static int launch_tile(GatherArgs& a, hipStream_t stream) {
         PMN_CHECK_LAUNCH();
         return (int)PMN_OK;
     };
-    // (EXACT = false on purpose: with a compile-time hypothesis count hipcc merges the walk's steps and spills)
-    return run(gather_tile_kernel<C, G, DT, false>);
+    return run(gather_tile_kernel<C, G, DT>);
 }
 
 int pmn_launch_gather_tile(GatherArgs& a, int C, int G, hipStream_t stream) {
