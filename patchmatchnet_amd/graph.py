@@ -35,13 +35,22 @@ class GraphedForward:
         self.replays = 0
 
     @staticmethod
-    def _signature(images: Sequence[torch.Tensor], intrinsics: torch.Tensor, features) -> Tuple:
+    def _alias_pattern(images: Sequence[torch.Tensor]) -> Tuple[int, ...]:
+        """For every image the index of the first image that is the same tensor (eval.py's encode-once path passes the reference
+        image N+1 times: FeatureNet is skipped and only Refinement reads an image)."""
+        first: Dict[int, int] = {}
+        return tuple(first.setdefault(im.data_ptr(), i) for i, im in enumerate(images))
+
+    @classmethod
+    def _signature(cls, images: Sequence[torch.Tensor], intrinsics: torch.Tensor, features) -> Tuple:
         feat = None if features is None else tuple(tuple((s, tuple(t.shape)) for s, t in sorted(f.items())) for f in features)
-        return tuple(tuple(i.shape) for i in images), tuple(intrinsics.shape), feat
+        return tuple(tuple(i.shape) for i in images), cls._alias_pattern(images), tuple(intrinsics.shape), feat
 
     def _capture(self, images, intrinsics, extrinsics, depth_min, depth_max, features):
         dev = intrinsics.device
-        static = dict(images=[torch.empty_like(i) for i in images], intrinsics=torch.empty_like(intrinsics),
+        pattern = self._alias_pattern(images)
+        bufs = [torch.empty_like(im) if pattern[i] == i else None for i, im in enumerate(images)]
+        static = dict(images=[bufs[pattern[i]] for i in range(len(images))], intrinsics=torch.empty_like(intrinsics),
                       extrinsics=torch.empty_like(extrinsics), depth_min=torch.empty_like(depth_min),
                       depth_max=torch.empty_like(depth_max),
                       features=None if features is None else [{s: torch.empty_like(t) for s, t in f.items()} for f in features])
@@ -67,9 +76,11 @@ class GraphedForward:
 
     @staticmethod
     def _fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
-        for dst, src in zip(static["images"], images):
-            if dst.data_ptr() != src.data_ptr():
+        done = set()
+        for dst, src in zip(static["images"], images):  # aliased inputs share one static buffer: copied once
+            if dst.data_ptr() not in done and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+            done.add(dst.data_ptr())
         static["intrinsics"].copy_(intrinsics, non_blocking=True)
         static["extrinsics"].copy_(extrinsics, non_blocking=True)
         static["depth_min"].copy_(depth_min, non_blocking=True)
