@@ -131,7 +131,12 @@ def stack_sources_nhwc(src_features: Sequence[torch.Tensor]) -> torch.Tensor:
     for i, f in enumerate(src_features):
         if tuple(f.shape) != (B, C, hs, ws):
             raise PmnError("all source feature maps of one stage must share a shape")
-        nchw_to_nhwc(f.contiguous(), buf[i])
+        v = f.permute(0, 2, 3, 1)
+        if f.is_cuda and f.dtype == torch.float32 and v.is_contiguous():
+            buf[i].copy_(v)  # an NCHW-shaped view of channels-last storage (the HIP FeatureNet's output): one plain copy, not a
+            #                  transpose to NCHW and back (eval.py's encode-once path hands such views over, 5 per stage)
+        else:
+            nchw_to_nhwc(f.contiguous(), buf[i])
     return buf
 
 
