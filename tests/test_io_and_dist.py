@@ -203,6 +203,23 @@ def test_uint8_images_are_the_float_images_times_255(tmp_path):
     assert v["image"].dtype == np.uint8 and v["view"] == 1
 
 
+def test_graph_replay_signature_tracks_shapes_and_aliasing():
+    """GraphedForward keys its captured graphs by everything a capture bakes in: input shapes, which inputs are the SAME tensor
+    (they share one static buffer) and the feature pyramids' shapes.  Pure host logic; the replay itself is a GPU test."""
+    from patchmatchnet_amd.graph import GraphedForward as G
+    a, b, c = torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 16, 8)
+    K = torch.zeros(1, 3, 3, 3)
+    assert G._alias_pattern([a, a, b, a, b]) == (0, 0, 2, 0, 2)
+    assert G._signature([a, b, b], K, None) != G._signature([a, b, a], K, None)      # different aliasing
+    assert G._signature([a, b, b], K, None) == G._signature([b, a, a], K, None)      # same shapes, same pattern
+    assert G._signature([a, b], K, None) != G._signature([c, c.clone()], K, None)    # different sizes
+    f1 = [{1: torch.zeros(1, 16, 4, 4), 2: torch.zeros(1, 32, 2, 2)}]
+    f2 = [{1: torch.zeros(1, 16, 4, 4), 2: torch.zeros(1, 32, 2, 3)}]
+    assert G._signature([a], K, f1) != G._signature([a], K, f2) and G._signature([a], K, f1) != G._signature([a], K, None)
+    with pytest.raises(_lib.PmnError):
+        G(None)([a], K, K, K, K)  # CPU tensors: there is no CPU path
+
+
 def test_ply_writer_layout(tmp_path):
     v = np.random.default_rng(0).random((11, 3)).astype(np.float32)
     c = (np.random.default_rng(1).random((11, 3)) * 255).astype(np.uint8)
