@@ -51,7 +51,7 @@ def warp_kernel_source_hash():
     measured on, and ``roofline.traffic`` is only reported when that is THIS tree (a stale PMC file would be a made-up number)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("gather_corr.hip", "gather_win.hip", "gather_lane.hip", "gather_common.hpp", "pmn_common.hpp"):
+    for name in ("gather_corr.hip", "gather_common.hpp", "pmn_common.hpp"):
         with open(os.path.join(ROOT, "patchmatchnet_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -12,7 +12,11 @@
  *     caller's current stream, NULL = default stream);
  *   - arguments named *_host are small HOST arrays (neighbour tables) copied into the kernel-argument segment;
  *   - returns PMN_OK (0) or a negative PMN_ERR_* code; nothing is launched when an argument check fails;
- *   - one process drives one GPU; entry points are re-entrant and keep no global state.
+ *   - entry points never block: each one only ENQUEUES kernels (no hip*Synchronize, no hipMalloc / hipFree, no hipMemcpy /
+ *     hipMemset, no stream or event waits), so a call costs microseconds, a whole forward is HIP-graph capturable, and a binding
+ *     may call in without releasing its interpreter lock (patchmatchnet_amd/_lib.py uses ctypes.PyDLL);
+ *     tests/test_abi.py::test_entry_points_never_block enforces it on the sources;
+ *   - entry points are re-entrant; the only process state is a cache of per-(kernel, device) launch attributes.
  *
  * Layouts
  *   feature maps    channels-last  [B, h, w, C]           (source views stacked: [N, B, hs, ws, C])
@@ -224,19 +228,6 @@ int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const 
                   const float *mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
                   float photo_thres, unsigned char *masks, float *xyz, double *depth_avg, int *geo_sum, void *stream);
 
-/* Process-wide tuning of pmn_warp_correlate (diagnostics / benchmarking; defaults are the measured best):
- *   key 1: kernel family.  bit 0 = windowed kernels where they cover the shape (0 = always the streaming kernels of
- *          gather_corr.hip); bit 4 = the first windowed form (gather_win.hip) instead of the lane = item engine
- *          (gather_lane.hip); bits 2 / 3 = keep the streaming kernel for the PixelwiseNet / the known-weights launches;
- *          bit 1 = gather_win.hip without the per-lane channel-quad rotation (bank-conflict A/B);
- *          bit 5 = the tile-window kernel (gather_tile.hip) for the known-weights launches;
- *   key 10: bytes of one of its two window buffers (multiple of 1024, 16384..65536);
- *   key 4: bytes of LDS each wave of gather_lane.hip may use for its source-map window (multiple of 1024, 1024..36864);
- *   key 6: gather_lane.hip build, 3 (168 registers, 3 waves per SIMD) or 2 (256 registers);
- *   keys 0, 2: window bytes of gather_win.hip (known-weights / PixelwiseNet kernels); keys 3, 5: timing ablations of
- *          gather_win.hip / gather_lane.hip (non-zero values skip work: results are then meaningless).
- * All kernel families compute bit-identical results (tests/test_gather_win.py).  Not thread-safe against concurrent launches. */
-int pmn_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

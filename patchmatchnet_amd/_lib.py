@@ -49,9 +49,18 @@ SIGNATURES = {
     "pmn_stage_projections": [_fp, _fp, _i, _i, _i, _f, _fp, _s],
     "pmn_stem": [_fp] * 6 + [_i] * 3 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
-    "pmn_set_tuning": [_i, _i],
     "pmn_fuse_view": [_fp, ctypes.c_longlong, _i, _hp, _i, _fp, _i, _i, _f, _f, _i, _f, _fp, _fp, _fp, _ip, _s],
 }
+
+# libpmn_hip_experimental.so only (include/pmn_hip_experimental.h; `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`)
+EXPERIMENTAL_SIGNATURES = {"pmn_set_tuning": [_i, _i]}
+EXPERIMENTAL_LIB_PATH = os.path.join(_CSRC, "libpmn_hip_experimental.so")
+
+
+def experimental() -> bool:
+    """True when this process opted into the research build (PMN_EXPERIMENTAL=1): the product never sets it."""
+    return os.environ.get("PMN_EXPERIMENTAL", "") == "1"
+
 
 _LIB: Optional[ctypes.CDLL] = None
 
@@ -62,7 +71,7 @@ class PmnError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "-j4"] + (["-B"] if force else [])
+    args = ["make", "-C", _CSRC, "-j4"] + (["-B"] if force else []) + (["EXPERIMENTAL=1"] if experimental() else [])
     if not verbose:
         args.insert(1, "-s")
     subprocess.check_call(args)
@@ -73,14 +82,17 @@ def lib() -> ctypes.CDLL:
     """Loads libpmn_hip.so; raises PmnError when it is missing (the product has no other compute path)."""
     global _LIB
     if _LIB is None:
-        if not os.path.isfile(LIB_PATH):
-            raise PmnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        path, sigs = LIB_PATH, SIGNATURES
+        if experimental():
+            path, sigs = EXPERIMENTAL_LIB_PATH, {**SIGNATURES, **EXPERIMENTAL_SIGNATURES}
+        if not os.path.isfile(path):
+            raise PmnError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"or `make -C patchmatchnet_amd/csrc` -- patchmatchnet_amd has no fallback path")
         # PyDLL: the entry points only enqueue kernels (microseconds, never a synchronisation), so they are called WITHOUT
         # releasing the GIL.  With CDLL each of the ~55 launches of a forward is a release/re-acquire, and every one of them is
         # an opening for eval.py's writer threads to take the GIL away from the launch thread (PMN_CTYPES=cdll restores that).
-        L = (ctypes.CDLL if os.environ.get("PMN_CTYPES", "") == "cdll" else ctypes.PyDLL)(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        L = (ctypes.CDLL if os.environ.get("PMN_CTYPES", "") == "cdll" else ctypes.PyDLL)(path)
+        for name, argtypes in sigs.items():
             try:
                 fn = getattr(L, name)
             except AttributeError as e:

@@ -279,10 +279,7 @@ static int launch_tiled_impl(const float* in, const float* w, const float* shift
     const size_t lds = (size_t)iw * iw * ((S == 2 && CC == 4) ? 4 : CC + 4) * sizeof(float);
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
     auto kern = conv_tiled_kernel<CIN, CC, COUT, COUTP, K, S, OUT_NCHW, UP>;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-        return PMN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + 15) / 16);
     hipLaunchKernelGGL(kern, dim3(blocks, COUTP / COUT), dim3(PMN_BLOCK), lds, st, in, w, shift, up, out, a);
     PMN_CHECK_LAUNCH();
@@ -674,10 +671,7 @@ static int launch_fpn_level(const float* x, const float* u, const float* w, cons
                             int H, int W, hipStream_t st) {
     const size_t lds = (size_t)(16 * 16 * (CIN + 4) + (UP ? 10 * 10 * (COUT + 4) : 0)) * sizeof(float);
     auto kern = fpn_level_kernel<CIN, COUT, CA, UP>;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-        return PMN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(PMN_BLOCK), lds, st, x, u, w, b, outA, outB, N, H, W);
     PMN_CHECK_LAUNCH();

@@ -189,10 +189,7 @@ static int launch_mfma(const float* in, const float* w, const float* shift, floa
     constexpr int TH = 2 * PG * NW, IW = 15 * S + (K - 1) * DIL + 1, IH = (TH - 1) * S + (K - 1) * DIL + 1;
     const size_t lds = (size_t)IH * IW * (CC + 4) * sizeof(float);
     auto kern = conv_mfma_kernel<CIN, CC, COUT, K, S, DIL, NW, PG, D, PLANAR>;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-        return PMN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, out_b,
                        a);

@@ -498,9 +498,7 @@ static int launch_w5(const float* in, const float* w, const float* shift, float*
     const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
     const size_t lds = (size_t)(8 * NG + 3) * 35 * 10 * sizeof(float);
     auto kern = conv5x5s2_wino_kernel<CIN, COUT>;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return PMN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((Wo + 15) / 16) * ((Ho + 4 * NG - 1) / (4 * NG));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo,
                        CIN / 8);

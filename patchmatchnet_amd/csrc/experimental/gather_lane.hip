@@ -28,7 +28,7 @@
 // Arithmetic and operation order are those of gather_corr.hip (pinned against the oracle / the reference's golden tensors), so
 // all three forms agree bit for bit (tests/test_gather_win.py).
 // Reference: models/module.py:130-181, models/patchmatch.py:192-217, :570, :695-702.
-#include "gather_common.hpp"
+#include "../gather_common.hpp"
 
 typedef float pmn_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char pmn_lds_char;        // LDS (ds_read / ds_write, never flat)

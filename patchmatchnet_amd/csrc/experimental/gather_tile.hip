@@ -17,7 +17,7 @@
 // Taps outside the window (bounding box larger than the window capacity) are loaded from global memory by the wave that meets
 // them.  Arithmetic and operation order are gather_corr.hip's, so the results agree bit for bit (tests/test_gather_win.py).
 // Reference: models/module.py:130-181, models/patchmatch.py:192-217, :570.
-#include "gather_common.hpp"
+#include "../gather_common.hpp"
 
 typedef float pmn_t4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char pmn_tlds;        // LDS (ds_read / ds_write, never flat)

@@ -26,7 +26,7 @@
 //     (MI355X_MICROARCH.md, LDS); each group is one 16-pixel row of items and lane i of a row walks its four channel quads in
 //     the order (j + i/4) % 4, so the 16 lanes of a group touch 16 different 16-byte slots whenever pixels i..i+3 of a row hit
 //     4 consecutive texels -- independent of the window's width and alignment.
-#include "gather_common.hpp"
+#include "../gather_common.hpp"
 
 typedef float pmn_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char pmn_lds_char;        // LDS (ds_read / ds_write, never flat)

@@ -586,13 +586,9 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     lds = (lds + 15) & ~(size_t)15;
     auto kern = gather_corr_kernel<C, G, MODE, DT, EXACT>;
     if (lds > 160 * 1024) return PMN_ERR_SHAPE;
-    static size_t lds_set = 0;  // per instantiation: largest dynamic-LDS size the attribute has been raised to (the call is a
-                                // driver round trip: once, not per launch)
-    if (lds > 48 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PMN_ERR_LAUNCH;
-        lds_set = lds;
+    if (lds > 48 * 1024) {
+        const int rc = pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc != PMN_OK) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     PMN_CHECK_LAUNCH();
@@ -659,12 +655,14 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     a.out = cost_out;
     a.B = B; a.N = N; a.D = D; a.h = h; a.w = w; a.hs = hs; a.ws = ws;
     a.vw_shift = vw_shift;
-    // kernel family (pmn_set_tuning key 1): bit 0 = windowed kernels where they cover the shape -- the lane = item engine
-    // (gather_lane.hip) or, with bit 4, the first windowed form (gather_win.hip) -- else the streaming kernel below.  Bits 2 / 3
-    // keep the streaming kernel for the PixelwiseNet / the known-weights launches only.
+#ifdef PMN_EXPERIMENTAL
+    // libpmn_hip_experimental.so only (`make EXPERIMENTAL=1`, include/pmn_hip_experimental.h): kernel family by pmn_set_tuning
+    // key 1 -- bit 0 = windowed kernels where they cover the shape (the lane = item engine, or with bit 4 the first windowed
+    // form), bits 2 / 3 keep the streaming kernel for the PixelwiseNet / the known-weights launches, bit 5 = the tile-window kernel.
+    // The product library has none of this: every launch is the streaming kernel below.
     const int flags = pmn_gather_flags();
     const bool pixelwise = view_weights_in == nullptr;
-    if ((flags & 32) && !pixelwise) {  // bit 5: the tile-window kernel (gather_tile.hip) for the known-weights launches
+    if ((flags & 32) && !pixelwise) {
         const int rc = pmn_launch_gather_tile(a, C, G, (hipStream_t)stream);
         if (rc != PMN_ERR_SHAPE) return rc;
     }
@@ -673,6 +671,7 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
                                     : pmn_launch_gather_lane(a, C, G, pixelwise, (hipStream_t)stream);
         if (rc != PMN_ERR_SHAPE) return rc;
     }
+#endif
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }

@@ -147,3 +147,28 @@ __device__ __forceinline__ int pmn_xcd_tile(int bid, int ntiles) {
         hipError_t e_ = hipGetLastError();                  \
         if (e_ != hipSuccess) return PMN_ERR_LAUNCH;        \
     } while (0)
+
+// Raises hipFuncAttributeMaxDynamicSharedMemorySize of ``func`` to ``bytes`` on the CURRENT device, once per (kernel, device,
+// size) -- the attribute is per device and the call is a driver round trip, so it is cached, keyed by device (a process may
+// launch on several GPUs: ops.py brackets every call with torch.cuda.device(tensor.device)) and guarded by a mutex (eval.py and
+// bench.py launch from one thread per process, but nothing in the ABI forbids two).
+#include <mutex>
+#include <vector>
+inline int pmn_raise_dynamic_lds(const void* func, size_t bytes) {
+    struct Entry { const void* func; int device; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PMN_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& e : seen)
+        if (e.func == func && e.device == dev) {
+            if (e.bytes >= bytes) return PMN_OK;
+            if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return PMN_ERR_LAUNCH;
+            e.bytes = bytes;
+            return PMN_OK;
+        }
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return PMN_ERR_LAUNCH;
+    seen.push_back({func, dev, bytes});
+    return PMN_OK;
+}

@@ -233,9 +233,7 @@ extern "C" int pmn_refine_tail(const float* x16, const float* w3, const float* s
     if (!x16 || !w3 || !s3 || !wr || !dnorm || !depth_min || !depth_max || !out || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
         return PMN_ERR_ARG;
     const size_t lds = (size_t)(20 * 424 + 18 * 256) * sizeof(float);  // 52.4 KB
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(refine_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return PMN_ERR_LAUNCH;
+    if (pmn_raise_dynamic_lds(reinterpret_cast<const void*>(refine_tail_kernel), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
     hipLaunchKernelGGL(refine_tail_kernel, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, x16, w3, s3, wr, dnorm,
                        depth_min, depth_max, out, B, H, W);

@@ -7,9 +7,14 @@ per input signature into a HIP graph (torch.cuda.CUDAGraph over the ctypes launc
 enqueues on the current stream, so the library is capturable as is) and replays it: one launch per sample, the interpreter is
 free for the I/O around it.
 
-Same results as the eager call, bit for bit, including the stage-3 random draw: the draw is a captured Philox kernel whose
-seed / offset are re-read from the generator at every replay, so ``torch.manual_seed(s)`` followed by a replay draws what the
-eager forward draws after ``torch.manual_seed(s)`` (tests/test_eval_gpu.py).
+Same results as the eager call, bit for bit, including the stage-3 random draw (reference models/patchmatch.py:61-62): the draw
+is NOT part of the graph.  Every call draws ``torch.rand(size=(B,48,H/8,W/8))`` eagerly on the caller's stream into the slot's
+static noise buffer -- the same call, at the same point of the generator's stream, as the eager forward makes -- and the
+captured forward reads that buffer (``noise=``).  A captured Philox kernel would instead re-read the generator's ONE pair of
+seed / offset device tensors at replay time; with several slots replaying on different streams, slot B's ``replay()`` refills that
+pair while slot A's draw may still be pending, and A would silently draw with B's offset.  The eager draw takes its
+seed / offset on the host at call time, so ``torch.manual_seed(s)`` followed by a call draws what the eager forward draws after
+``torch.manual_seed(s)`` whatever else is in flight (tests/test_eval_gpu.py).
 
 Reference: models/net.py:176-301 (PatchmatchNet.forward) is what one graph holds; eval.py:56-64 is the loop that replays it.
 """
@@ -32,7 +37,7 @@ class GraphedForward:
     def __init__(self, model, max_graphs: int = 8) -> None:
         self.model, self.max_graphs = model, max_graphs
         self.cache: Dict[Tuple, Tuple] = {}
-        self.replays = 0
+        self.replays = self.captures = self.evictions = 0
 
     @staticmethod
     def _alias_pattern(images: Sequence[torch.Tensor]) -> Tuple[int, ...]:
@@ -53,14 +58,17 @@ class GraphedForward:
         static = dict(images=[bufs[pattern[i]] for i in range(len(images))], intrinsics=torch.empty_like(intrinsics),
                       extrinsics=torch.empty_like(extrinsics), depth_min=torch.empty_like(depth_min),
                       depth_max=torch.empty_like(depth_max),
+                      noise=torch.empty((images[0].shape[0], 48, images[0].shape[2] // 8, images[0].shape[3] // 8),
+                                        dtype=torch.float32, device=dev),
                       features=None if features is None else [{s: torch.empty_like(t) for s, t in f.items()} for f in features])
         self._fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features)
 
         def run():
             return self.model(list(static["images"]), static["intrinsics"], static["extrinsics"], static["depth_min"],
-                              static["depth_max"], features=static["features"])
+                              static["depth_max"], features=static["features"], noise=static["noise"])
 
         rng = torch.cuda.get_rng_state(dev)  # warm-up and capture must not advance the caller's random stream
+        self._draw(static)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # one eager pass off the capture: lazy kernel attributes, weight packing, allocator warm-up
@@ -73,6 +81,12 @@ class GraphedForward:
             depth, confidence, _ = run()
         torch.cuda.set_rng_state(rng, dev)
         return graph, static, (depth, confidence)
+
+    @staticmethod
+    def _draw(static) -> None:
+        """The stage-3 draw of this sample, eagerly on the current stream: torch.rand with the eager forward's size and dtype, so
+        the default generator advances exactly as it does there (models/patchmatch.py:61-62)."""
+        torch.rand(size=tuple(static["noise"].shape), out=static["noise"])
 
     @staticmethod
     def _fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
@@ -99,13 +113,19 @@ class GraphedForward:
             depth, confidence, _ = self.model(images, intrinsics, extrinsics, depth_min, depth_max, features=features)
             return depth, confidence
         key = self._signature(images, intrinsics, features)
-        entry = self.cache.get(key)
+        entry = self.cache.pop(key, None)
         if entry is None:
-            if len(self.cache) >= self.max_graphs:  # a new signature per call would pin memory without bound
+            # least-recently-USED eviction (a hit re-inserts its key at the end): a scan that alternates between a few image sizes
+            # keeps all of them; ``captures`` lets a caller see a workload that defeats the cache (one capture per call)
+            if len(self.cache) >= self.max_graphs:
                 self.cache.pop(next(iter(self.cache)))
-            entry = self.cache[key] = self._capture(images, intrinsics, extrinsics, depth_min, depth_max, features)
+                self.evictions += 1
+            entry = self._capture(images, intrinsics, extrinsics, depth_min, depth_max, features)
+            self.captures += 1
+        self.cache[key] = entry
         graph, static, out = entry
         self._fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features)
+        self._draw(static)
         graph.replay()
         self.replays += 1
         return out

@@ -52,8 +52,12 @@ DEFAULT_FLAGS = 0  # the library default: streaming kernels for every launch (th
 
 
 def set_tuning(key: int, value: int) -> None:
-    """pmn_set_tuning: process-wide knobs of pmn_warp_correlate (window bytes per wave, kernel family); both kernel
-    families give bit-identical results (tests/test_gather_win.py)."""
+    """pmn_set_tuning of the EXPERIMENTAL build only (include/pmn_hip_experimental.h; PMN_EXPERIMENTAL=1): selects one of the
+    research kernel families of pmn_warp_correlate / their window sizes; all families give bit-identical results
+    (tests/test_gather_win.py).  The product library has neither the kernels nor the symbol."""
+    if not _lib.experimental():
+        raise PmnError("pmn_set_tuning exists only in libpmn_hip_experimental.so: build with `make -C patchmatchnet_amd/csrc "
+                       "EXPERIMENTAL=1` and run with PMN_EXPERIMENTAL=1")
     check(_lib.lib().pmn_set_tuning(int(key), int(value)), "pmn_set_tuning")
 
 

@@ -16,6 +16,11 @@ Outputs (committed):
   evaluation_io.npz        Evaluation.forward at its own boundary (models/patchmatch.py:145-239): the reference's grid / weight /
                            depth_sample / view_weights inputs and (depth, score, view_weights) outputs of stage-3 iteration 1
                            (PixelwiseNet) and stage-2 iteration 1 of the default cascade (``--only evaluation`` writes just this).
+  cfg2_scene.npz           BASELINE configs[1] at FULL size (1600x1200, N=5, iters 1,2,2) on the photo-consistent scene of
+                           tests/synth.py (``render_scene``, seed 0; stage-3 noise seed 1234): the reference's final depth,
+                           confidence, every stage / iteration depth, stage-3 view weights and the integer confidence index,
+                           FREE-RUNNING from the images (``--only scene``; ~15 s of CPU).  Inputs regenerate from the seeds;
+                           ``scene_digest`` pins them.
 """
 import os
 import sys
@@ -87,6 +92,32 @@ def dump_evaluation_io(path, model, n_views=3, H=96, W=128, seed=1234):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def dump_scene(path, model, n_views=6, H=1200, W=1600, scene_seed=0, noise_seed=1234):
+    """The reference itself, end to end from images, on the configuration every number is quoted on."""
+    import synth
+    imgs, intr, extr, depth_gt = synth.render_scene(n_views, H, W, scene_seed)
+    dmin, dmax = np.array([425.0], np.float32), np.array([935.0], np.float32)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(noise_seed))
+    depth, conf, dpm, tr = refutil.trace_reference_forward(
+        model, [i.clone() for i in imgs], torch.from_numpy(intr).clone(), torch.from_numpy(extr).clone(),
+        torch.from_numpy(dmin), torch.from_numpy(dmax), noise)
+    score = tr[1][-1]["score"]
+    D = score.shape[1]
+    idx = (score * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).sum(1).long().clamp(0, D - 1)  # net.py:294-297
+    out = {"scene_seed": np.int32(scene_seed), "noise_seed": np.int32(noise_seed), "n_views": np.int32(n_views),
+           "H": np.int32(H), "W": np.int32(W), "scene_digest": np.array(synth.scene_digest(imgs)),
+           "depth": t2n(depth), "confidence": t2n(conf), "depth_index": t2n(idx).astype(np.int8),
+           "view_weights": t2n(tr[3][0]["view_weights"])}
+    for s in (1, 2, 3):
+        for it, d in enumerate(dpm[s]):
+            out[f"s{s}_it{it + 1}_depth_out"] = t2n(d)
+    np.savez_compressed(path, **out)
+    gt = depth_gt.numpy()
+    err = np.abs(t2n(depth)[0, 0] - gt)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "| reference vs ground truth: median %.3f mm, p90 %.3f mm"
+          % (np.median(err), np.quantile(err, 0.9)))
+
+
 def dump_ops(path):
     _, _, ref_module = refutil.import_reference()
     g = torch.Generator().manual_seed(7)
@@ -120,6 +151,9 @@ def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "evaluation":
         dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
         return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "scene":
+        dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
+        return
     sd = refutil.state_dict_numpy(model)
     p = os.path.join(HERE, "params_000007.npz")
     np.savez_compressed(p, **sd)
@@ -146,6 +180,7 @@ def main():
     dump_cascade(os.path.join(HERE, "cascade_variant_b2.npz"), variant, 4, 48, 64, B=2, seed=4321)
     dump_ops(os.path.join(HERE, "ops_small.npz"))
     dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
+    dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
 
 
 if __name__ == "__main__":

@@ -89,3 +89,86 @@ def write_scan(root: str, scan: str, n_views: int, H: int, W: int, n_src: int = 
             others = [u for u in range(n_views) if u != v][:max(n_src, 1)]
             f.write("%d\n%d " % (v, len(others)) + " ".join("%d %.2f" % (u, 100.0 - u) for u in others) + "\n")
     return d
+
+
+# ---- photo-consistent scene ---------------------------------------------------------------
+# An analytic height field z = f(X, Y) in the reference camera's frame (= world: the reference extrinsic is the identity),
+# textured by a band-limited procedural pattern defined ON THE SURFACE, and rendered into every camera by inverse warping
+# (per-pixel ray / surface intersection, Newton).  Every view therefore sees the same surface colours: the matching cost along
+# a pixel's ray has ONE mode at the true depth, unlike the rolled-noise images of ``synthetic_images`` whose content is
+# unrelated to the cameras.  Images are quantised to k/255 like decoded JPEG / PNG data, which also makes them reproducible
+# across hosts (libm / SIMD sin() differences of an ulp cannot move a rounding except with probability ~1e-13 per pixel);
+# ``scene_digest`` is stored in the golden so that a host that renders something else fails loudly.
+
+SCENE_Z0, SCENE_AMP, SCENE_LX, SCENE_LY, SCENE_TILT = 650.0, 25.0, 260.0, 210.0, 0.10
+
+
+def scene_height(X, Y):
+    """Height field and its gradient: z = z0 + A sin(2 pi X / Lx) cos(2 pi Y / Ly) + tilt * X."""
+    kx, ky = 2.0 * math.pi / SCENE_LX, 2.0 * math.pi / SCENE_LY
+    sx, cx, sy, cy = torch.sin(kx * X), torch.cos(kx * X), torch.sin(ky * Y), torch.cos(ky * Y)
+    z = SCENE_Z0 + SCENE_AMP * sx * cy + SCENE_TILT * X
+    return z, SCENE_AMP * kx * cx * cy + SCENE_TILT, -SCENE_AMP * ky * sx * sy
+
+
+def scene_texture(X, Y, seed: int, n_waves: int = 40):
+    """[3, ...] colours in [0,1]: per channel a sum of plane waves on the surface coordinates (wavelengths 1.5 - 80 mm,
+    log-uniform, random directions / phases); band-limited, so sampling it at 0.22 mm per pixel is alias-free."""
+    g = torch.Generator().manual_seed(10007 * seed + 17)
+    lam = 1.5 * (80.0 / 1.5) ** torch.rand(n_waves, generator=g, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.rand(n_waves, generator=g, dtype=torch.float64)
+    phase = 2.0 * math.pi * torch.rand(3, n_waves, generator=g, dtype=torch.float64)
+    amp = (0.6 + 0.8 * torch.rand(3, n_waves, generator=g, dtype=torch.float64)) * (0.2 / math.sqrt(n_waves / 2.0))
+    fx, fy = (2.0 * math.pi / lam * torch.cos(ang)).to(X.device), (2.0 * math.pi / lam * torch.sin(ang)).to(X.device)
+    phase, amp = phase.to(X.device), amp.to(X.device)
+    out = torch.full((3,) + tuple(X.shape), 0.5, dtype=torch.float64, device=X.device)
+    for k in range(n_waves):
+        arg = fx[k] * X + fy[k] * Y
+        s, c = torch.sin(arg), torch.cos(arg)
+        for ch in range(3):  # sin(arg + phase) from one sin / cos pair per wave
+            out[ch] += amp[ch, k] * (s * math.cos(float(phase[ch, k])) + c * math.sin(float(phase[ch, k])))
+    return out.clamp_(0.0, 1.0)
+
+
+def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quantise: bool = True):
+    """Photo-consistent synthetic sample for ``synthetic_cameras(n_views, H, W)``.
+
+    Returns (images: n_views x [1,3,H,W] float32 in {k/255}, intrinsics [1,N,3,3], extrinsics [1,N,4,4],
+    depth_gt [H,W] float32 = the surface's depth in the reference view (view 0))."""
+    intr, extr = synthetic_cameras(n_views, H, W)
+    dev = torch.device(device)
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=dev), torch.arange(W, dtype=torch.float64, device=dev),
+                          indexing="ij")
+    images, depth_gt = [], None
+    for i in range(n_views):
+        K = torch.from_numpy(intr[0, i].astype(np.float64))
+        E = torch.from_numpy(extr[0, i].astype(np.float64))
+        R, t = E[:3, :3], E[:3, 3]
+        Cc = -(R.T @ t)  # camera centre in world coordinates
+        Kinv = torch.linalg.inv(K)
+        M = R.T @ Kinv   # ray direction in world coordinates = M @ (u, v, 1)
+        dx = float(M[0, 0]) * u + float(M[0, 1]) * v + float(M[0, 2])
+        dy = float(M[1, 0]) * u + float(M[1, 1]) * v + float(M[1, 2])
+        dz = float(M[2, 0]) * u + float(M[2, 1]) * v + float(M[2, 2])
+        s = (SCENE_Z0 - float(Cc[2])) / dz
+        for _ in range(10):  # Newton on g(s) = C_z + s d_z - f(x(s), y(s)); |grad f . d_xy / d_z| < 1 on this rig
+            X, Y = float(Cc[0]) + s * dx, float(Cc[1]) + s * dy
+            z, fx, fy = scene_height(X, Y)
+            s = s - (float(Cc[2]) + s * dz - z) / (dz - fx * dx - fy * dy)
+        X, Y = float(Cc[0]) + s * dx, float(Cc[1]) + s * dy
+        img = scene_texture(X, Y, seed)
+        if quantise:
+            img = torch.round(img * 255.0) / 255.0
+        images.append(img.to(torch.float32)[None].contiguous())
+        if i == 0:
+            depth_gt = (float(Cc[2]) + s * dz).to(torch.float32)  # E_0 = I: camera depth = world z
+    return images, intr, extr, depth_gt
+
+
+def scene_digest(images) -> str:
+    """sha256 over the uint8 form of the rendered views (what the golden was computed on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for im in images:
+        h.update(torch.round(im.detach().cpu() * 255.0).to(torch.uint8).numpy().tobytes())
+    return h.hexdigest()

@@ -42,10 +42,31 @@ def test_library_builds_loads_and_exports_every_symbol():
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     for name in _declared():
         assert name in exported, name
+    # ... and nothing else: the research families and their pmn_set_tuning live in libpmn_hip_experimental.so only
+    assert {e for e in exported if e.startswith("pmn_")} == set(_declared())
+    assert b"gather_lane_kernel" not in open(_lib.LIB_PATH, "rb").read()
     assert L.pmn_error_string(-2).decode().startswith("unsupported shape")
     # the code object really targets gfx950
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
+
+
+def test_entry_points_never_block():
+    """include/pmn_hip.h's contract: an entry point only ENQUEUES on the caller's stream -- it never synchronises, allocates or
+    copies.  _lib.py relies on it (ctypes.PyDLL: calls keep the GIL; a blocking call would stall eval.py's writer and
+    pin-memory threads and could deadlock against a thread waiting for the GIL inside the runtime), and so does HIP-graph
+    capture of the whole forward.  Enforced on the sources: none of the blocking runtime calls may appear in csrc/."""
+    csrc = os.path.join(ROOT, "patchmatchnet_amd", "csrc")
+    banned = re.compile(r"\bhip(DeviceSynchronize|StreamSynchronize|EventSynchronize|Malloc\w*|Free\w*|"
+                        r"Mem(?:cpy|set)(?:(?!Async)\w)*|HostMalloc|HostFree|StreamWaitEvent|StreamCreate\w*)\s*\(")
+    for dirpath, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".hpp")):
+                text = re.sub(r"//.*", "", open(os.path.join(dirpath, f)).read())
+                text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+                m = banned.search(text)
+                assert m is None, (f, m.group(0))
+    assert "never block" in open(HEADER).read()
 
 
 def test_argument_checks_do_not_launch():

@@ -1,4 +1,7 @@
-"""pmn_warp_correlate has three kernel families -- lane = item (csrc/gather_lane.hip, the default) and the first windowed
+"""OPT-IN (research build): runs only with PMN_EXPERIMENTAL=1 and `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`
+(libpmn_hip_experimental.so); skipped in the product configuration, whose library has the streaming family alone.
+
+pmn_warp_correlate has three kernel families -- lane = item (csrc/gather_lane.hip, the default) and the first windowed
 form (csrc/gather_win.hip), both taking their taps from wave-private LDS windows of the source maps, and streaming (csrc/gather_corr.hip: taps straight from HBM/L1).  They implement the same arithmetic in the
 same order (reference models/module.py:130-181, models/patchmatch.py:192-217, :570, :695-702), so they must agree BIT FOR
 BIT on any input; the streaming family is the one pinned against the oracle / the reference's golden tensors in
@@ -20,6 +23,9 @@ CG = {64: 8, 32: 8, 16: 4}  # channels -> groups (reference models/net.py:153-15
 def _gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
+    from patchmatchnet_amd import _lib
+    if not _lib.experimental():
+        pytest.skip("research kernel families: opt in with PMN_EXPERIMENTAL=1 (+ make EXPERIMENTAL=1)")
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops
     P.lib()
