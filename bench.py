@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- depth-maps/sec of PatchmatchNet inference on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -21,8 +21,16 @@ the ~3.5 ms of Python launch work per forward from the critical path.
 
 Extra objects on the line: ``roofline`` for the dominant kernel (pmn_warp_correlate; HIP events on the launch stream around
 its launches in an eager single-stream pass of the same run -- launches inside a replayed graph cannot be bracketed and
-overlapped kernels have no duration of their own; algorithmic bytes per SURVEY.md 8(d)) and, at N=1, ``cpu_baseline`` = the
-CPU oracle (oracle/, the checker -- never the thing shipped) timed on the host cores over one full-size hot-path pass.
+overlapped kernels have no duration of their own; algorithmic bytes per SURVEY.md 8(d); next to the contract's HBM fraction the
+line carries the bound that actually holds, the vector-L1 / texture-addresser path: ``tap_bytes_per_step``, ``l1_achieved``,
+``l1_frac``) and, at N=1, ``cpu_baseline`` = the WHOLE forward on the host cores in the metric's own unit (depth-maps/s):
+FeatureNet and Refinement as the plain torch modules on the CPU backend, the cascade and the confidence epilogue through the CPU
+oracle (oracle/, the checker -- never the thing shipped), at 8 / 64 / all threads.  ``steady_state`` repeats the timed region's
+loop for ~2 s (same mode) so that a multi-second figure at settled clocks is on the line beside the K-step ``value``.
+
+Inputs: the photo-consistent scene of tests/synth.render_scene (an analytic surface textured procedurally and rendered into every
+camera; one texture seed per sample) -- the scene tests/golden/cfg2_scene.npz pins against the reference.  ``--scene rolled`` =
+rounds 1-2's images (one noise image rolled per view, unrelated to the cameras).
 """
 import argparse
 import json
@@ -81,16 +89,22 @@ def load_weights(model):
     return "random init"
 
 
-def make_samples(n_samples, n_views, H, W, device, rank):
+def make_samples(n_samples, n_views, H, W, device, rank, scene="surface"):
+    """``n_samples`` distinct synthetic samples resident on ``device``.  scene="surface": tests/synth.render_scene (rendered on the
+    device in float64, quantised to k/255 like decoded image files); "rolled": the images of rounds 1-2."""
     import synth
     intr, extr = synth.synthetic_cameras(n_views, H, W)
     samples = []
     for s in range(n_samples):
-        g = torch.Generator().manual_seed(1000 * rank + s)
-        base = torch.rand(1, 3, H, W, generator=g)
-        base = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(base, (2, 2, 2, 2), mode="reflect"), 5, 1)
-        imgs = [(torch.roll(base, shifts=4 * v, dims=3) + 0.02 * torch.rand(1, 3, H, W, generator=g)).clamp(0, 1)
-                .contiguous().to(device) for v in range(n_views)]
+        if scene == "surface":
+            imgs, _, _, _ = synth.render_scene(n_views, H, W, seed=1000 * rank + s, device=device)
+            imgs = [im.to(device).contiguous() for im in imgs]
+        else:
+            g = torch.Generator().manual_seed(1000 * rank + s)
+            base = torch.rand(1, 3, H, W, generator=g)
+            base = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(base, (2, 2, 2, 2), mode="reflect"), 5, 1)
+            imgs = [(torch.roll(base, shifts=4 * v, dims=3) + 0.02 * torch.rand(1, 3, H, W, generator=g)).clamp(0, 1)
+                    .contiguous().to(device) for v in range(n_views)]
         samples.append(dict(images=imgs, intrinsics=torch.from_numpy(intr).to(device),
                             extrinsics=torch.from_numpy(extr).to(device),
                             depth_min=torch.tensor([425.0], device=device),
@@ -98,31 +112,92 @@ def make_samples(n_samples, n_views, H, W, device, rank):
     return samples
 
 
-def cpu_baseline(H, W, n_src):
-    """The CPU oracle (a port of the reference arithmetic; oracle/) on one full-size hot-path pass: the cascade from
-    FeatureNet outputs to the stage-1 depth at 1600x1200, N=5, iterations (1,2,2)."""
+def cpu_baseline(H, W, n_src, model_kw):
+    """The whole forward on the host cores, in the metric's unit: FeatureNet.forward / Refinement.forward = the plain torch modules
+    of patchmatchnet_amd/net.py on the CPU backend (reference models/net.py:9-122), cascade + confidence epilogue = the CPU oracle
+    (a port of models/patchmatch.py, models/module.py:130-196, models/net.py:221-299).  One forward per thread count."""
     import synth
     from oracle import oracle as O
+    from patchmatchnet_amd.net import FeatureNet, Refinement
     with np.load(os.path.join(ROOT, "tests", "golden", "params_000007.npz")) as z:
         params = {k: z[k] for k in z.files}
-    f3 = synth.synthetic_features(n_src + 1, 64, H // 8, W // 8, 0)
-    f2 = synth.synthetic_features(n_src + 1, 32, H // 4, W // 4, 1)
-    f1 = synth.synthetic_features(n_src + 1, 16, H // 2, W // 2, 2)
-    feats = [{3: f3[i].numpy(), 2: f2[i].numpy(), 1: f1[i].numpy()} for i in range(n_src + 1)]
-    intr, extr = synth.synthetic_cameras(n_src + 1, H, W)
-    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(1)).numpy()
+    feature, refine = FeatureNet().eval(), Refinement().eval()
+    feature.load_state_dict({k[len("feature."):]: torch.from_numpy(v) for k, v in params.items() if k.startswith("feature.")})
+    refine.load_state_dict({k[len("upsample_net."):]: torch.from_numpy(v) for k, v in params.items() if k.startswith("upsample_net.")})
+    imgs, intr, extr, _ = synth.render_scene(n_src + 1, H, W, seed=0)
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(1234)).numpy()
+    dmin, dmax = np.array([425.0], np.float32), np.array([935.0], np.float32)
     cores = os.cpu_count() or 1
-    O.set_num_threads(cores)
-    t0 = time.perf_counter()
-    O.cascade(params, feats, intr, extr, np.array([425.0], np.float32), np.array([935.0], np.float32), noise)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "hot-path passes/s (cascade only: FeatureNet and Refinement excluded -- NOT comparable "
-                                       "with `value`, which is the whole forward)", "cores": cores, "kind": "port",
-            "sample": f"1 hot-path pass (cascade stage3->1 from feature maps) at {W}x{H}, N={n_src}, iters (1,2,2): {dt:.1f} s on "
-                      f"{cores} threads (C oracle, OpenMP)",
+    configs = O.default_stage_configs(model_kw["patchmatch_interval_scale"], model_kw["propagation_range"],
+                                      model_kw["patchmatch_iteration"], model_kw["patchmatch_num_sample"],
+                                      model_kw["propagate_neighbors"], model_kw["evaluate_neighbors"])
+
+    def forward(threads):
+        torch.set_num_threads(threads)
+        O.set_num_threads(threads)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            feats = [{k: v.numpy() for k, v in feature(im).items()} for im in imgs]
+            t1 = time.perf_counter()
+            d1, score, _ = O.cascade(params, feats, intr, extr, dmin, dmax, noise, configs=configs)
+            O.confidence(score, (H, W))
+            t2 = time.perf_counter()
+            refine(imgs[0], torch.from_numpy(np.ascontiguousarray(d1)), torch.from_numpy(dmin), torch.from_numpy(dmax))
+        t3 = time.perf_counter()
+        return t3 - t0, (t1 - t0, t2 - t1, t3 - t2)
+
+    prev = torch.get_num_threads()
+    runs = {}
+    for th in sorted({min(8, cores), min(64, cores), cores}):
+        dt, parts = forward(th)
+        runs[th] = {"seconds": round(dt, 2), "depth_maps_per_s": round(1.0 / dt, 4),
+                    "featurenet_cascade_refinement_s": [round(x, 2) for x in parts]}
+    torch.set_num_threads(prev)
+    best = min(runs, key=lambda th: runs[th]["seconds"])
+    return {"value": runs[best]["depth_maps_per_s"], "unit": "depth-maps/s (whole forward: FeatureNet + cascade + confidence + "
+            "Refinement; same unit as `value`)", "cores": best, "kind": "port",
+            "sample": f"1 forward per thread count at {W}x{H}, N={n_src}, iters (1,2,2), photo-consistent scene seed 0; "
+                      f"threads -> seconds: " + ", ".join(f"{th}: {r['seconds']}" for th, r in runs.items()) +
+                      f"; host has {cores} hardware threads; FeatureNet / Refinement = torch CPU backend, cascade = C/OpenMP oracle",
+            "threads": {str(th): r for th, r in runs.items()},
             "reference_measured_elsewhere": REFERENCE_CPU_MEASURED,
             "rocm_reference_denominator": "unmeasurable on the bench box: the north star's '>= 4x the reference on PyTorch-ROCm' needs "
                                           "the reference sources, which cannot travel (DESIGN.md section 4)"}
+
+
+def self_launch(n_ranks):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU, free rendezvous port on 127.0.0.1),
+    rank 0 inherits stdout and prints the single JSON line; the exit code is the worst rank's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver: dmabuf IPC only (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            failed = [p for p in procs if p.poll() not in (None, 0)]
+            if failed:  # one rank died: the others would wait in a collective forever
+                rc = failed[0].returncode
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    raise SystemExit(rc or max((p.returncode or 0) for p in procs))
 
 
 def main():
@@ -141,21 +216,28 @@ def main():
                     help="issue every kernel from Python on one stream (the round-1 mode) instead of replaying HIP graphs")
     ap.add_argument("--roofline-steps", type=int, default=24,
                     help="eager single-stream steps after the timed region that carry the HIP events of the roofline figure")
+    ap.add_argument("--scene", choices=("surface", "rolled"), default="surface",
+                    help="surface = photo-consistent rendered scene (tests/synth.render_scene); rolled = rounds 1-2's images")
+    ap.add_argument("--steady-seconds", type=float, default=2.0,
+                    help="length of the extra steady-state pass reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)  # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     if os.environ.get("PMN_DIST_BACKEND", "nccl") != "nccl":
         local_rank %= torch.cuda.device_count()  # several ranks on one GPU (control-flow test only)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ  # by torch.distributed.run / self_launch: then the process group exists even for one rank
+    if launched:                            # (world 1 over RCCL exercises the same init / collectives as world 8: tests/test_bench_gpu.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         # nccl (= RCCL over xGMI) is the product's backend; PMN_DIST_BACKEND=gloo exists so that the multi-rank control flow can be
         # exercised with several ranks on ONE GPU (collectives then stage through the host)
         backend = os.environ.get("PMN_DIST_BACKEND", "nccl")
@@ -163,11 +245,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    on_host = world > 1 and dist.get_backend() != "nccl"
+    on_host = launched and dist.get_backend() != "nccl"
 
     def reduce_scalar(x, op):
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_host else device)
-        if world > 1:
+        if launched:
             dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -179,7 +261,7 @@ def main():
     weights = load_weights(model)
     model = model.to(device).eval()
     H, W, n_src = args.height, args.width, args.views
-    samples = make_samples(max(args.samples, 1), n_src + 1, H, W, device, rank)
+    samples = make_samples(max(args.samples, 1), n_src + 1, H, W, device, rank, args.scene)
 
     def step(i):
         s = samples[i % len(samples)]
@@ -187,13 +269,13 @@ def main():
                      s["depth_max"])
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
     def close_region(outs):
         """The per-scan gather of the final maps before fusion: the only collective of the path (RCCL over xGMI)."""
-        if world > 1:
+        if launched:
             mine = torch.stack([outs[0][0, 0], outs[1][0]], 0).contiguous()
             if on_host:
                 mine = mine.cpu()
@@ -212,17 +294,23 @@ def main():
     with torch.no_grad():
         launch_note = None
 
+        region = {}  # "run": callable(steps) -> seconds, the timed loop in the mode that produced `value` (re-used by steady_state)
+
         def timed_eager():
+            def run(steps):
+                barrier()
+                t0 = time.perf_counter()
+                outs = None
+                for i in range(steps):
+                    depth, conf, _ = step(i)
+                    outs = (depth, conf)
+                close_region(outs)
+                return time.perf_counter() - t0
+
             for i in range(args.warmup):
                 step(i)
-            barrier()
-            t0 = time.perf_counter()
-            outs = None
-            for i in range(args.steps):
-                depth, conf, _ = step(i)
-                outs = (depth, conf)
-            close_region(outs)
-            return time.perf_counter() - t0
+            region["run"] = run
+            return run(args.steps)
 
         def timed_in_flight():
             """Returns the elapsed time, or None when some rank could not capture its graphs (decided collectively before the
@@ -247,15 +335,20 @@ def main():
                 err = str(e).split("\n")[0][:120] or "RuntimeError"
             if reduce_scalar(0.0 if err else 1.0, dist.ReduceOp.MIN) < 1.0:
                 return None, err or "capture failed on another rank"
-            barrier()
-            t0 = time.perf_counter()
-            outs = None
-            for i in range(args.steps):
-                outs = replay(i)
-            for st in streams:
-                main_stream.wait_stream(st)
-            close_region(outs)
-            return time.perf_counter() - t0, ""
+
+            def run(steps):
+                barrier()
+                t0 = time.perf_counter()
+                outs = None
+                for i in range(steps):
+                    outs = replay(i)
+                for st in streams:
+                    main_stream.wait_stream(st)
+                close_region(outs)
+                return time.perf_counter() - t0
+
+            region["run"] = run
+            return run(args.steps), ""
 
         if args.eager:
             elapsed = timed_eager()
@@ -266,6 +359,13 @@ def main():
                 launch_note = "python, one stream (HIP-graph capture failed: %s)" % why
                 S = 1
                 elapsed = timed_eager()
+
+        # ---- steady state: the same loop for ~args.steady_seconds (clocks settled, thousands of launches), reported beside `value`
+        steady = None
+        if args.steady_seconds > 0:
+            n_steady = max(int(args.steady_seconds / (elapsed / args.steps)), args.steps)
+            n_steady = int(reduce_scalar(float(n_steady), dist.ReduceOp.MAX))  # every rank runs the same count
+            steady = (n_steady, reduce_scalar(region["run"](n_steady), dist.ReduceOp.MAX))
 
         # ---- roofline pass: HIP events around the pmn_warp_correlate launches ------------------------------------------------
         # Launches inside a replayed graph cannot be bracketed by events, and kernels of two overlapped forwards do not have a
@@ -295,6 +395,15 @@ def main():
         k_ms = sum(r[0] for r in recs)  # over the `sampled` steps that carried events
         k_bytes = sum(r[1] for r in recs)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # what actually bounds the kernel: every bilinear corner of every (view, pixel, hypothesis) is a
+        # C*4-byte read through the CU's vector L1 / texture addresser: 4 corners x N x h x w x D x C x 4 B per launch
+        def tap_bytes(tag):
+            f = tag.split("_")  # C{C}_D{D}_{h}x{w}_N{N}_{kind}
+            C_, D_, (h_, w_), N_ = int(f[0][1:]), int(f[1][1:]), map(int, f[2].split("x")), int(f[3][1:])
+            return 4 * N_ * h_ * w_ * D_ * C_ * 4
+        k_taps = sum(tap_bytes(r[2]) for r in recs)
+        L1_PEAK_GBS = 64 * 256 * 2.4  # 64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s (MI355X_MICROARCH.md)
+        l1_achieved = k_taps / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         per = {}
         for ms, nb, tag in recs:
             a = per.setdefault(tag, [0.0, 0, 0])
@@ -327,9 +436,14 @@ def main():
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
                                    f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
                        "distinct_samples": len(samples),
+                       "scene": "photo-consistent rendered surface (tests/synth.render_scene), one texture seed per sample"
+                                if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
                        "in_flight": S, "launch": launch_note or ("python, one stream" if args.eager else
                        f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU")},
+            "steady_state": None if steady is None else {
+                "steps": steady[0], "seconds": round(steady[1], 3), "value": round(world * steady[0] / steady[1], 2),
+                "note": "the timed region's loop repeated for ~%.0f s in the same mode (not the contract's K steps)" % args.steady_seconds},
             "single_stream_eager": {"value": round(R / eager_elapsed, 2), "ms_per_step": round(eager_elapsed / R * 1e3, 4),
                                     "steps": R, "note": "this rank, one sample at a time, kernels issued from Python (the "
                                     "round-1 mode; = one sample's latency); the roofline events were recorded in this pass"},
@@ -337,6 +451,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "frac_of_measured_achievable": round(achieved / 6290.0, 5),  # 6.29 TB/s measured achievable
+                         "bound_actual": "vector L1 / texture addresser (64 B/clk/CU): HBM traffic is below the algorithmic bytes, "
+                                         "the taps are re-read ~37x through L1 (DESIGN.md section 4)",
+                         "tap_bytes_per_step": int(k_taps / sampled), "l1_achieved": round(l1_achieved, 1),
+                         "l1_peak": round(L1_PEAK_GBS, 1), "l1_frac": round(l1_achieved / L1_PEAK_GBS, 4),
                          "traffic": traffic,
                          "traffic_unit": traffic_note,
                          "measured_in": "eager single-stream pass of the same run (see single_stream_eager): a replayed "
@@ -348,9 +466,9 @@ def main():
                                        for k, v in per.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(H, W, n_src)
+            line["cpu_baseline"] = cpu_baseline(H, W, n_src, DEFAULT_KW)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

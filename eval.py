@@ -201,8 +201,12 @@ def _encode_once_ok(dataset, scan, light, views):
     return h % 8 == 0 and w % 8 == 0
 
 
-def save_depth(args, rank, world, device):
+def save_depth(args, rank, world, device, on_scan_done=None):
     """Runs the network over this rank's reference views and writes depth / confidence maps (reference eval.py:20-82).
+
+    ``on_scan_done(scan, produced)`` is called as soon as every (scan, light) group of a scan has been inferred (--output_type both:
+    the scan is fused right there and its [2,H,W] maps leave the device -- the first fused.ply appears after the first scan, and a
+    rank holds one scan's maps at a time instead of the whole dataset's).
 
     Per-scan feature cache: every image of a scan is a source view of ~num_views other samples,
     and the reference decodes AND re-encodes it each time.  With --feature_cache > 0 a (scan, light) group is processed in two
@@ -242,58 +246,79 @@ def save_depth(args, rank, world, device):
     produced = {}  # (scan, ref view) -> [2,H,W] on device, kept for the per-scan gather
     done, total = 0, len(dataset)
     writer = MapWriter(device, args.file_format, workers=max(args.writer_threads, 1))
-    with torch.no_grad():
-        for (scan, light), indices in dataset.groups().items():
-            views = dataset.views_of(indices)
-            encode_once = args.feature_cache > 0 and args.batch_size == 1 and _encode_once_ok(dataset, scan, light, views)
-            subset = torch.utils.data.Subset(dataset, indices)
-            if not encode_once:
-                dataset.load_images = True
-                loader = DataLoader(subset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
-                                    drop_last=False, pin_memory=True)
-                for sample in DevicePrefetcher(loader, device):
-                    start = time.time()
-                    _seed_sample(args, dataset, sample)
-                    tensors = list(sample["images"]) + [sample[k] for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
-                    st, (depth, confidence) = run_sample(tensors, list(sample["images"]), sample["intrinsics"],
-                                                         sample["extrinsics"], sample["depth_min"], sample["depth_max"])
-                    with torch.cuda.stream(st):
-                        _write_maps(args, sample, depth, confidence, produced, writer)
-                    done += len(sample["filename"])
-                    print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
-                continue
-            # pass 1: decode + encode every view once (FeatureNet in batches of up to 4 images)
-            start = time.time()
-            pyramids, images = {}, {}
-            refs = {dataset.metas[i][2] for i in indices}
-            vloader = DataLoader(MVSViewDataset(dataset, scan, light, views), batch_size=4, shuffle=False,
-                                 num_workers=args.num_workers, drop_last=False, pin_memory=True)
-            for batch in DevicePrefetcher(vloader, device, keys=("image",)):
-                imgs = batch["image"]
-                f = model.feature.forward_hip(imgs)
-                for j, v in enumerate(batch["view"].tolist()):
-                    pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
-                    if v in refs:
-                        images[v] = imgs[j:j + 1]  # Refinement reads the reference image
-            print("{}{}: {} views encoded once, time = {:.3f}".format(scan, "/" + light if light else "", len(views),
-                                                                     time.time() - start))
-            # pass 2: the samples, from cameras only
-            dataset.load_images = False
-            loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=0, drop_last=False)  # camera text files only
-            for sample in loader:
+    by_scan = {}
+    for (scan, light), indices in dataset.groups().items():
+        by_scan.setdefault(scan, []).append((light, indices))
+
+    def scan_finished(scan):
+        if on_scan_done is not None:
+            for st in streams:  # the scan's last maps are still being produced on the slot streams
+                main_stream.wait_stream(st)
+            on_scan_done(scan, produced)
+            for key in [k for k in produced if k[0] == scan]:
+                del produced[key]
+
+    def run_group(scan, light, indices):
+        nonlocal done
+        views = dataset.views_of(indices)
+        encode_once = args.feature_cache > 0 and args.batch_size == 1 and _encode_once_ok(dataset, scan, light, views)
+        subset = torch.utils.data.Subset(dataset, indices)
+        if not encode_once:
+            dataset.load_images = True
+            loader = DataLoader(subset, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
+                                drop_last=False, pin_memory=True)
+            for sample in DevicePrefetcher(loader, device):
                 start = time.time()
-                ids = [int(v) for v in sample["view_ids"][0]]
-                ref_img = images[ids[0]]
                 _seed_sample(args, dataset, sample)
-                cams = [sample[k].to(device) for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
-                st, (depth, confidence) = run_sample(cams, [ref_img] * len(ids), *cams, features=[pyramids[v] for v in ids])
+                tensors = list(sample["images"]) + [sample[k] for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
+                st, (depth, confidence) = run_sample(tensors, list(sample["images"]), sample["intrinsics"],
+                                                     sample["extrinsics"], sample["depth_min"], sample["depth_max"])
                 with torch.cuda.stream(st):
                     _write_maps(args, sample, depth, confidence, produced, writer)
-                done += 1
+                done += len(sample["filename"])
                 print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
-            dataset.load_images = True
-            for st in streams:  # the next group's encode pass (main stream) frees the pyramids the slots are still reading
-                main_stream.wait_stream(st)
+            return
+        # pass 1: decode + encode every view once (FeatureNet in batches of up to 4 images)
+        start = time.time()
+        pyramids, images = {}, {}
+        refs = {dataset.metas[i][2] for i in indices}
+        vloader = DataLoader(MVSViewDataset(dataset, scan, light, views), batch_size=4, shuffle=False,
+                             num_workers=args.num_workers, drop_last=False, pin_memory=True)
+        for batch in DevicePrefetcher(vloader, device, keys=("image",)):
+            imgs = batch["image"]
+            f = model.feature.forward_hip(imgs)
+            for j, v in enumerate(batch["view"].tolist()):
+                pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
+                if v in refs:
+                    images[v] = imgs[j:j + 1]  # Refinement reads the reference image
+        print("{}{}: {} views encoded once, time = {:.3f}".format(scan, "/" + light if light else "", len(views),
+                                                                 time.time() - start))
+        # pass 2: the samples, from cameras only
+        dataset.load_images = False
+        loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=0, drop_last=False)  # camera text files only
+        for sample in loader:
+            start = time.time()
+            ids = [int(v) for v in sample["view_ids"][0]]
+            ref_img = images[ids[0]]
+            _seed_sample(args, dataset, sample)
+            cams = [sample[k].to(device) for k in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
+            st, (depth, confidence) = run_sample(cams, [ref_img] * len(ids), *cams, features=[pyramids[v] for v in ids])
+            with torch.cuda.stream(st):
+                _write_maps(args, sample, depth, confidence, produced, writer)
+            done += 1
+            print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
+        dataset.load_images = True
+        for st in streams:  # the next group's encode pass (main stream) frees the pyramids the slots are still reading
+            main_stream.wait_stream(st)
+        del pyramids, images
+
+    with torch.no_grad():
+        # scan by scan in the scan list's order on EVERY rank: also a rank that owns no reference view of a scan (fewer views than
+        # ranks) reaches scan_finished, whose fusion step holds the per-scan collective
+        for scan in dataset.scans:
+            for light, indices in by_scan.get(scan, []):
+                run_group(scan, light, indices)
+            scan_finished(scan)
     for st in streams:
         main_stream.wait_stream(st)
     writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
@@ -321,24 +346,31 @@ def filter_depth(args, scan, produced, rank, world, device):
     ref_ids = [r for r, _ in pairs]
     view_ids = sorted(set(ref_ids) | {s for _, ss in pairs for s in ss})
     cams, sizes = _scan_cameras(args, scan, view_ids)
-    if len(set(sizes.values())) != 1:
-        raise P.PmnError("{}: views of different sizes after --image_max_dim ({}); the fused-on-device path needs one size per "
-                         "scan".format(scan or args.input_folder, sorted(set(sizes.values()))))
-    H, W = sizes[view_ids[0]]
+    # one size per scan (DTU, ETH3D): the [V,2,H,W] buffer; mixed sizes (--image_max_dim on a scan whose images differ, Tanks &
+    # Temples style collections): flat slots, every view packed at its own size -- the reference likewise reads every view's maps
+    # at their own size (eval.py:203-237)
+    mixed = len(set(sizes.values())) != 1
+    H, W = max(h for h, _ in sizes.values()), max(w for _, w in sizes.values())
     buf, slot_of = None, {}
     if produced is not None:
         mine = pdist.shard_views(ref_ids, rank, world)
         missing = [vid for vid in mine if (scan, vid) not in produced]
         if missing:
             raise P.PmnError("{}: this rank did not produce the maps of views {} it owns".format(scan, missing))
-        buf, slot_of = pdist.gather_scan_buffer({vid: produced[(scan, vid)] for vid in mine}, ref_ids, H, W, device)
+        buf, slot_of = pdist.gather_scan_buffer({vid: produced[(scan, vid)] for vid in mine}, ref_ids, H, W, device, flat=mixed)
     extra = [vid for vid in view_ids if vid not in slot_of]
     if extra:  # fusion-only run, or a source view that is nobody's reference view: read the files
         maps = []
         for vid in extra:
             d = read_map(os.path.join(args.output_folder, scan, "depth_est/{:0>8}{}".format(vid, args.file_format))).squeeze(2)
             c = read_map(os.path.join(args.output_folder, scan, "confidence/{:0>8}{}".format(vid, args.file_format))).squeeze(2)
-            maps.append(torch.from_numpy(np.stack((d, c)).astype(np.float32)))
+            m = torch.from_numpy(np.stack((d, c)).astype(np.float32))
+            if m.shape[1:] != sizes[vid]:
+                raise P.PmnError("{}: the maps of view {} on disk are {}x{}, its image (after --image_max_dim) is {}x{}".format(
+                    scan or args.input_folder, vid, m.shape[1], m.shape[2], *sizes[vid]))
+            if mixed:
+                m = torch.nn.functional.pad(m.reshape(-1), (0, 2 * H * W - m.numel()))
+            maps.append(m)
         more = torch.stack(maps).to(device)
         base = 0 if buf is None else buf.shape[0]
         buf = more if buf is None else torch.cat((buf, more), 0)
@@ -348,7 +380,7 @@ def filter_depth(args, scan, produced, rank, world, device):
     images = {ref: read_image(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(ref)), args.image_max_dim)[0]
               for ref, _ in my_pairs}
     vertices, colors, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                                args.geo_mask_thres, args.photo_thres)
+                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None)
     os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
     for ref, (photo, geo, final) in masks.items():
         save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_photo.png".format(ref)), photo)
@@ -412,7 +444,8 @@ def build_parser():
     p.add_argument("--geo_mask_thres", type=int, default=5, help="threshold for geometric consistency filtering")
     p.add_argument("--photo_thres", type=float, default=0.5, help="threshold for photometric consistency filtering")
     # additions
-    p.add_argument("--num_workers", type=int, default=4, help="DataLoader worker processes per rank")
+    p.add_argument("--num_workers", type=int, default=-1,
+                   help="DataLoader (JPEG decode) worker processes per rank; -1 = the host's hardware threads / ranks, minus two")
     p.add_argument("--sample_seed", type=int, default=-1,
                    help=">= 0: re-seed the device RNG per sample from (this value, scan, reference view) so the stage-3 random "
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
@@ -443,10 +476,15 @@ def main(argv=None):
         raise P.PmnError("eval.py needs a ROCm GPU: the learned-PatchMatch path has no CPU fallback")
     rank, world, device = pdist.init_from_env("cuda")
 
-    produced = None
-    if args.output_type in ("depth", "both"):
-        produced = save_depth(args, rank, world, device)
-    if args.output_type in ("fusion", "both"):
+    if args.num_workers < 0:  # decode workers: the host's cores shared between the ranks of the node
+        args.num_workers = max((os.cpu_count() or 4) // max(world, 1) - 2, 2)
+    if args.output_type == "depth":
+        save_depth(args, rank, world, device)
+    elif args.output_type == "both":
+        # every scan is fused as soon as its maps exist, straight from device memory (the per-scan all-gather)
+        save_depth(args, rank, world, device,
+                   on_scan_done=lambda scan, produced: filter_depth(args, scan, produced, rank, world, device))
+    else:
         if args.scan_list:
             if not os.path.isfile(args.scan_list):
                 raise Exception("Invalid scan list file: {}".format(args.scan_list))
@@ -455,8 +493,8 @@ def main(argv=None):
         else:
             scans = [""]
         for scan in scans:
-            filter_depth(args, scan, produced, rank, world, device)
-    if world > 1:
+            filter_depth(args, scan, None, rank, world, device)
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

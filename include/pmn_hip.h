@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 11
+#define PMN_ABI_VERSION 12
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -217,15 +217,18 @@ int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, con
  * (reference eval.py:86-190 reproject_with_depth / check_geometric_consistency, :207-281 filter_depth), one launch, a thread per
  * reference pixel.  maps: the per-scan buffer [V][2][H][W] (slot v = depth, confidence of view v -- what the per-scan all-gather
  * leaves on every rank), slot_stride floats between slots; ref_slot and src_slots_host[n_src] (HOST ints, n_src <=
- * PMN_MAX_FUSE_SRC) index it; all views share H x W.  mats (DEVICE float32, built by patchmatchnet_amd/fusion.py with numpy's own
+ * PMN_MAX_FUSE_SRC) index it.  H x W is the REFERENCE view's size; src_hw_host (HOST int[2*n_src]: height, width of every source
+ * view's maps; NULL = all H x W) gives every source map its own size, as the reference reads every view's file at its own size
+ * (eval.py:203-237; --image_max_dim on a scan with mixed image sizes): slot v holds depth [h_v][w_v] then confidence [h_v][w_v]
+ * packed at the start of the slot, slot_stride >= 2*h*w of the largest view.  mats (DEVICE float32, built by patchmatchnet_amd/fusion.py with numpy's own
  * float32 inverse / matmul so that they are the reference's matrices): 48 floats for the reference view -- [0..8] inverse(K_ref),
  * [9..17] K_ref, [18..33] inverse(E_ref) -- then 64 floats per source view -- [0..15] E_src @ inverse(E_ref), [16..24] K_src,
  * [25..33] inverse(K_src), [34..49] E_ref @ inverse(E_src).  Outputs: masks [3][H][W] bytes (photo = confidence > photo_thres,
  * geo = consistent sources >= geo_mask_thres, final = both), xyz [H][W][3] world point of the averaged depth (meaningful where
  * final), optional depth_avg [H][W] float64 and geo_sum [H][W] int32.  Numeric types follow the reference's numpy dtype flow;
  * cv2.remap(INTER_LINEAR) is restated with OpenCV's 1/32-pixel fixed-point coordinates (oracle/fusion_oracle.py). */
-int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const int *src_slots_host, int n_src,
-                  const float *mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
+int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const int *src_slots_host,
+                  const int *src_hw_host, int n_src, const float *mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
                   float photo_thres, unsigned char *masks, float *xyz, double *depth_avg, int *geo_sum, void *stream);
 
 

@@ -53,6 +53,14 @@ def lib() -> ctypes.CDLL:
                                         ctypes.c_float, ctypes.c_float, ctypes.c_int, _f32p]
         L.pmo_neighbor_positions.argtypes = [_f32p, _i32p] + [ctypes.c_int] * 3 + [_f32p, _f32p]
         L.pmo_neighbor_gather.argtypes = [_f32p, _f32p, _i32p] + [ctypes.c_int] * 4 + [_f32p]
+        i64 = ctypes.c_int64
+        L.pmo_feature_corr.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, _f32p]
+        L.pmo_normalised_inverse_depth.argtypes = [_f32p, i64, ctypes.c_float, ctypes.c_float, _f32p]
+        L.pmo_depth_weight.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, i64, ctypes.c_float, _f32p]
+        L.pmo_weight_normalise.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, i64]
+        L.pmo_weighted_neighbor_sum.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, i64, _f32p]
+        L.pmo_view_accumulate.argtypes = [_f32p, _f32p, ctypes.c_int, i64, _f32p, _f32p]
+        L.pmo_view_normalise.argtypes = [_f32p, _f32p, ctypes.c_int, i64]
         _LIB = L
     return _LIB
 
@@ -233,12 +241,18 @@ def depth_weight(depth_sample: np.ndarray, depth_min: np.ndarray, depth_max: np.
                  table: np.ndarray, interval_scale: float) -> np.ndarray:
     """models/patchmatch.py:650-669 -> [B,D,K,h,w]."""
     one = np.float32(1.0)
-    inv_min = (one / depth_min.astype(np.float32)).reshape(-1, 1, 1, 1)
-    inv_max = (one / depth_max.astype(np.float32)).reshape(-1, 1, 1, 1)
-    x = (one / depth_sample - inv_max) / (inv_min - inv_max)
+    B, D, h, w = depth_sample.shape
+    K = table.shape[0]
+    ds = _c(depth_sample)
+    x = np.empty_like(ds)
+    for b in range(B):
+        inv_min, inv_max = one / np.float32(depth_min[b]), one / np.float32(depth_max[b])
+        lib().pmo_normalised_inverse_depth(_p(ds[b]), D * h * w, float(inv_min), float(inv_max), _p(x[b]))
     x1 = neighbor_gather(x, eval_offsets, table)  # [B,D,K,h,w]
-    x1 = np.abs(x1 - x[:, :, None]) / np.float32(interval_scale)
-    return _sigmoid(np.float32(4.0) - np.float32(2.0) * np.clip(x1, 0, 4).astype(np.float32))
+    out = np.empty_like(x1)
+    for b in range(B):
+        lib().pmo_depth_weight(_p(x[b]), _p(x1[b]), D, K, h * w, float(np.float32(interval_scale)), _p(out[b]))
+    return out
 
 
 def feature_weight_net(ref_feature: np.ndarray, eval_offsets: np.ndarray, table: np.ndarray, G: int, params,
@@ -246,9 +260,11 @@ def feature_weight_net(ref_feature: np.ndarray, eval_offsets: np.ndarray, table:
     """models/patchmatch.py:613-624 -> [B,K,h,w]."""
     B, C, h, w = ref_feature.shape
     K = table.shape[0]
-    nb = neighbor_gather(ref_feature, eval_offsets, table).reshape(B, G, C // G, K, h, w)
-    ref = ref_feature.reshape(B, G, C // G, 1, h, w)
-    corr = (nb * ref).mean(axis=2, dtype=np.float32)  # [B,G,K,h,w]
+    nb = neighbor_gather(ref_feature, eval_offsets, table)  # [B,C,K,h,w]
+    ref = _c(ref_feature)
+    corr = np.empty((B, G, K, h, w), np.float32)  # (nb * ref).view(B,G,C/G,K,h,w).mean(2)
+    for b in range(B):
+        lib().pmo_feature_corr(_p(nb[b]), _p(ref[b]), C, G, K, h * w, _p(corr[b]))
     return pointwise_mlp(corr, params, prefix, "similarity", sigmoid=True)
 
 
@@ -257,7 +273,12 @@ def similarity_net(similarity: np.ndarray, eval_offsets: np.ndarray, table: np.n
     """models/patchmatch.py:565-577.  Returns (score_pre_softmax [B,D,h,w], pointwise cost [B,D,h,w])."""
     cost = pointwise_mlp(similarity, params, prefix, "similarity", sigmoid=False)
     nb = neighbor_gather(cost, eval_offsets, table)  # [B,D,K,h,w]
-    return (nb * weight).sum(axis=2, dtype=np.float32), cost
+    B, D, K, h, w = nb.shape
+    weight = _c(weight)
+    score = np.empty((B, D, h, w), np.float32)  # (nb * weight).sum(2)
+    for b in range(B):
+        lib().pmo_weighted_neighbor_sum(_p(nb[b]), _p(weight[b]), D, K, h * w, _p(score[b]))
+    return score, cost
 
 
 def softmax_over_depth(score: np.ndarray) -> np.ndarray:
@@ -291,7 +312,7 @@ def evaluation(ref_feature, src_features: Sequence[np.ndarray], ref_proj, src_pr
     assert len(src_features) == len(src_projs)
     if have_vw:
         assert len(src_features) == view_weights.shape[1]
-    weight_sum = np.full((B, 1, 1, h, w), 1e-5, np.float32)
+    weight_sum = np.full((B, h, w), 1e-5, np.float32)
     sim_sum = np.zeros((B, G, D, h, w), np.float32)
     vw_list, arg_list = [], []
     for i, (src_fea, src_proj) in enumerate(zip(src_features, src_projs)):
@@ -302,9 +323,12 @@ def evaluation(ref_feature, src_features: Sequence[np.ndarray], ref_proj, src_pr
             vw, arg = pixelwise_net(sim, params, f"{prefix}.pixel_wise_net")
             vw_list.append(vw)
             arg_list.append(arg)
-        sim_sum += sim * vw[:, :, None]
-        weight_sum += vw[:, :, None]
-    similarity = sim_sum / weight_sum
+        vw = _c(vw)
+        for b in range(B):  # sim_sum += sim * vw; weight_sum += vw
+            lib().pmo_view_accumulate(_p(sim[b]), _p(vw[b]), G * D, h * w, _p(sim_sum[b]), _p(weight_sum[b]))
+    for b in range(B):  # similarity = sim_sum / weight_sum
+        lib().pmo_view_normalise(_p(sim_sum[b]), _p(weight_sum[b]), G * D, h * w)
+    similarity = sim_sum
     score, cost = similarity_net(similarity, eval_offsets, table, weight, params, f"{prefix}.similarity_net")
     prob = softmax_over_depth(score)
     out = {"similarity": similarity, "cost": cost, "score": prob}
@@ -328,8 +352,9 @@ def dilated_conv3x3(x: np.ndarray, weight: np.ndarray, bias: np.ndarray, dilatio
     out = np.zeros((B, weight.shape[0], h, w), np.float32)
     for ky in range(3):
         for kx in range(3):
-            patch = xp[:, :, ky * d:ky * d + h, kx * d:kx * d + w]
-            out += np.einsum("oc,bchw->bohw", weight[:, :, ky, kx].astype(np.float32), patch, dtype=np.float32)
+            patch = np.ascontiguousarray(xp[:, :, ky * d:ky * d + h, kx * d:kx * d + w]).reshape(B, C, h * w)
+            # [O,C] @ [B,C,hw] through BLAS sgemm (threaded); tap order ky, kx as before
+            out += np.matmul(weight[:, :, ky, kx].astype(np.float32), patch).reshape(B, -1, h, w)
     return out + bias.astype(np.float32).reshape(1, -1, 1, 1)
 
 
@@ -381,8 +406,9 @@ def patchmatch_stage(cfg: StageConfig, params, ref_feature, src_features, ref_pr
         if cfg.propagate_neighbors > 0 and not (cfg.stage == 1 and it == cfg.iterations):
             depth_sample = propagation(depth_sample, propa_offsets, ptab)
         weight = depth_weight(depth_sample, depth_min, depth_max, eval_offsets, etab, cfg.interval_scale)
-        weight = weight * feature_weight[:, None]
-        weight = weight / weight.sum(axis=2, keepdims=True, dtype=np.float32)
+        fw = _c(feature_weight)
+        for b in range(weight.shape[0]):  # weight = weight * feature_weight.unsqueeze(1); weight /= weight.sum(2)
+            lib().pmo_weight_normalise(_p(weight[b]), _p(fw[b]), weight.shape[1], weight.shape[2], weight.shape[3] * weight.shape[4])
         ev = evaluation(ref_feature, src_features, ref_proj, src_projs, depth_sample, eval_offsets, etab, weight,
                         view_weights, is_inverse, cfg.G, params, f"{prefix}.evaluation")
         if trace is not None:

@@ -244,3 +244,91 @@ void pmo_neighbor_gather(const float *in, const float *offs, const int *base, in
                     out[((size_t)c * K + k) * hw + (size_t)y * w + x] = bil_fetch_zeros(in + c * hw, h, w, &b);
             }
 }
+
+/* ---- element-wise glue of one PatchMatch iteration, OpenMP-parallel over pixels ------------------------------------------
+ * The same IEEE fp32 operations, in the same order, as the numpy expressions they replaced in oracle.py (reductions over
+ * a non-innermost axis add slab by slab, i.e. sequentially in the reduced index); kept in C so that bench.py's
+ * cpu_baseline scales with the host's cores instead of idling on serial numpy temporaries. */
+
+/* a11 (patchmatch.py:618-620): corr[G,K,hw] = mean over the C/G channels of a group of nb[C,K,hw] * ref[C,hw] */
+void pmo_feature_corr(const float *nb, const float *ref, int C, int G, int K, int64_t hw, float *out) {
+    const int cg = C / G;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p)
+        for (int g = 0; g < G; ++g)
+            for (int k = 0; k < K; ++k) {
+                float acc = 0.0f;
+                for (int i = 0; i < cg; ++i) {
+                    int c = g * cg + i;
+                    acc += nb[((size_t)c * K + k) * hw + p] * ref[(size_t)c * hw + p];
+                }
+                out[((size_t)g * K + k) * hw + p] = acc / (float)cg;
+            }
+}
+
+/* a12 (patchmatch.py:650-669): x = (1/ds - 1/dmax) / (1/dmin - 1/dmax) for ds[D,hw] */
+void pmo_normalised_inverse_depth(const float *ds, int64_t n, float inv_min, float inv_max, float *x) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) x[i] = (1.0f / ds[i] - inv_max) / (inv_min - inv_max);
+}
+
+/* a12 (patchmatch.py:662-669): w[D,K,hw] = sigmoid(4 - 2 * clamp(|x1 - x| / interval, 0, 4)), x1[D,K,hw], x[D,hw] */
+void pmo_depth_weight(const float *x, const float *x1, int D, int K, int64_t hw, float interval, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p)
+        for (int d = 0; d < D; ++d)
+            for (int k = 0; k < K; ++k) {
+                size_t o = ((size_t)d * K + k) * hw + p;
+                float v = fabsf(x1[o] - x[(size_t)d * hw + p]) / interval;
+                v = v < 0.0f ? 0.0f : (v > 4.0f ? 4.0f : v);
+                float z = 4.0f - 2.0f * v;
+                out[o] = 1.0f / (1.0f + expf(-z));
+            }
+}
+
+/* a13 (patchmatch.py:502-510): weight = depth_weight * feature_weight; weight /= sum_k weight.   dw[D,K,hw] in place, fw[K,hw] */
+void pmo_weight_normalise(float *dw, const float *fw, int D, int K, int64_t hw) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p)
+        for (int d = 0; d < D; ++d) {
+            float s = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                size_t o = ((size_t)d * K + k) * hw + p;
+                dw[o] = dw[o] * fw[(size_t)k * hw + p];
+                s = k == 0 ? dw[o] : s + dw[o];
+            }
+            for (int k = 0; k < K; ++k) dw[((size_t)d * K + k) * hw + p] /= s;
+        }
+}
+
+/* a6 (patchmatch.py:576-577): out[D,hw] = sum_k nb[D,K,hw] * weight[D,K,hw] */
+void pmo_weighted_neighbor_sum(const float *nb, const float *weight, int D, int K, int64_t hw, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p)
+        for (int d = 0; d < D; ++d) {
+            float s = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                size_t o = ((size_t)d * K + k) * hw + p;
+                float t = nb[o] * weight[o];
+                s = k == 0 ? t : s + t;
+            }
+            out[(size_t)d * hw + p] = s;
+        }
+}
+
+/* a5 (patchmatch.py:209-217): sim_sum[GD,hw] += sim[GD,hw] * vw[hw]; weight_sum[hw] += vw[hw] */
+void pmo_view_accumulate(const float *sim, const float *vw, int GD, int64_t hw, float *sim_sum, float *weight_sum) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p) {
+        float v = vw[p];
+        for (int j = 0; j < GD; ++j) sim_sum[(size_t)j * hw + p] += sim[(size_t)j * hw + p] * v;
+        weight_sum[p] += v;
+    }
+}
+
+/* a5 (patchmatch.py:223-224): similarity = sim_sum / weight_sum, in place */
+void pmo_view_normalise(float *sim_sum, const float *weight_sum, int GD, int64_t hw) {
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < hw; ++p)
+        for (int j = 0; j < GD; ++j) sim_sum[(size_t)j * hw + p] /= weight_sum[p];
+}

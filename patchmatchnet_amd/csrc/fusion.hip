@@ -4,8 +4,8 @@
 // Reference: eval.py:86-145 (reproject_with_depth), :148-190 (check_geometric_consistency), :207-281 (filter_depth: photo
 // mask, geometric mask sum, averaged depth, final mask, world points).  The reference does this per (ref, src) pair in
 // single-threaded numpy + cv2.remap over maps re-read from disk; here a thread owns one reference pixel and walks the source
-// views with the running mask count / depth sum in registers, reading the per-scan [V][2][H][W] buffer that the all-gather
-// leaves in HBM.  The numeric types follow the reference's numpy dtype flow (float32 camera matrices promoted to float64 in
+// views with the running mask count / depth sum in registers, reading the per-scan slot buffer that the all-gather
+// leaves in HBM (slot v = depth, confidence of view v, each view at its own size).  The numeric types follow the reference's numpy dtype flow (float32 camera matrices promoted to float64 in
 // the products, float32 casts of the map coordinates / re-projected depth and positions, float32 threshold on the relative
 // depth difference, float64 on the pixel distance) and cv2.remap's INTER_LINEAR is restated with its 1/32-pixel fixed-point
 // coordinates (OpenCV imgwarp.cpp, INTER_BITS = 5; oracle/fusion_oracle.py carries the same restatement).
@@ -17,8 +17,8 @@
 #define PMN_FUSE_SRC_FLOATS 64
 
 struct FuseArgs {
-    const float* maps;     // [V][2][H][W]: slot v = (depth, confidence)
-    long long slot_stride; // floats between slots (>= 2*H*W)
+    const float* maps;     // slot v = (depth [h_v][w_v], confidence [h_v][w_v]) packed at the start of the slot
+    long long slot_stride; // floats between slots (>= 2*h*w of the largest view)
     const float* mats;     // device floats: ref block (48) + n_src blocks (64), layout in include/pmn_hip.h
     unsigned char* masks;  // [3][H][W]: photo, geo, final
     float* xyz;            // [H][W][3] world points (meaningful where final)
@@ -27,6 +27,8 @@ struct FuseArgs {
     int ref_slot, n_src, H, W, geo_mask_thres;
     float geo_pixel_thres, geo_depth_thres, photo_thres;
     int src_slot[PMN_MAX_FUSE_SRC];
+    int src_h[PMN_MAX_FUSE_SRC], src_w[PMN_MAX_FUSE_SRC];  // every source map at its OWN size (reference eval.py:236-237 reads
+                                                           // each view's file as it is; cv2.remap samples it at that size)
 };
 
 // cv2.remap(src, x, y, INTER_LINEAR), float32 single channel, BORDER_CONSTANT 0
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void fuse_view_kernel(const FuseArgs a) {
         const double sx = dot4(T, rx, ry, rz, 1.0), sy = dot4(T + 4, rx, ry, rz, 1.0), sz = dot4(T + 8, rx, ry, rz, 1.0);
         const double kx = dot3(Ks, sx, sy, sz), ky = dot3(Ks + 3, sx, sy, sz), kz = dot3(Ks + 6, sx, sy, sz);
         const double xs = kx / kz, ys = ky / kz;
-        const float sampled = remap_linear_cv2(src, a.H, a.W, (float)xs, (float)ys);
+        const float sampled = remap_linear_cv2(src, a.src_h[s], a.src_w[s], (float)xs, (float)ys);
         // back-project with the SAMPLED source depth (float64 coordinates, as the reference)
         const double bx = xs * (double)sampled, by = ys * (double)sampled, bz = (double)sampled;
         const double qx = dot3(Ksi, bx, by, bz), qy = dot3(Ksi + 3, bx, by, bz), qz = dot3(Ksi + 6, bx, by, bz);
@@ -116,8 +118,8 @@ __global__ __launch_bounds__(256) void fuse_view_kernel(const FuseArgs a) {
     a.xyz[3 * p + 2] = (float)dot4(Eri + 8, cx, cy, cz, 1.0);
 }
 
-extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_slot, const int* src_slots_host, int n_src,
-                             const float* mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
+extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_slot, const int* src_slots_host,
+                             const int* src_hw_host, int n_src, const float* mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
                              float photo_thres, unsigned char* masks, float* xyz, double* depth_avg, int* geo_sum,
                              void* stream) {
     if (!maps || !mats || !masks || !xyz || (n_src > 0 && !src_slots_host)) return PMN_ERR_ARG;
@@ -143,6 +145,9 @@ extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_s
     for (int i = 0; i < n_src; ++i) {
         if (src_slots_host[i] < 0) return PMN_ERR_ARG;
         a.src_slot[i] = src_slots_host[i];
+        a.src_h[i] = src_hw_host ? src_hw_host[2 * i] : H;
+        a.src_w[i] = src_hw_host ? src_hw_host[2 * i + 1] : W;
+        if (a.src_h[i] < 1 || a.src_w[i] < 1 || slot_stride < 2LL * a.src_h[i] * a.src_w[i]) return PMN_ERR_ARG;
     }
     hipLaunchKernelGGL(fuse_view_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
     PMN_CHECK_LAUNCH();

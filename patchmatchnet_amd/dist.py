@@ -26,11 +26,17 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    # launched by torch.distributed.run (WORLD_SIZE set, also for a single rank): the process group exists and every collective
+    # below runs through it -- one rank over RCCL exercises the same library path as eight
+    if "WORLD_SIZE" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29578")
         # PMN_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests/test_eval_gpu.py: RCCL needs a device per rank)
         backend = os.environ.get("PMN_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -51,29 +57,36 @@ def shard_views(view_ids: List[int], rank: int, world: int) -> List[int]:
     return view_ids[a:b]
 
 
-def gather_scan_buffer(local: Dict[int, torch.Tensor], view_ids: List[int], H: int, W: int, device: torch.device
-                       ) -> Tuple[torch.Tensor, Dict[int, int]]:
-    """All-gather the [2,H,W] (depth, confidence) maps of one scan into ONE buffer.
+def gather_scan_buffer(local: Dict[int, torch.Tensor], view_ids: List[int], H: int, W: int, device: torch.device,
+                       flat: bool = False) -> Tuple[torch.Tensor, Dict[int, int]]:
+    """All-gather the [2,h,w] (depth, confidence) maps of one scan into ONE buffer.
 
     ``local`` holds this rank's maps keyed by view id; ``view_ids`` is the scan's full (ordered) list, owned in blocks as in
     ``shard_views``.  Every rank contributes ceil(len/world) slots (padding slots are zero); one ``all_gather_into_tensor``
     moves them -- ~15 MB per 1600x1200 view, i.e. 107.5 MB per rank for a 49-view DTU scan on 8 GPUs.  Returns
-    (buffer [world * slots, 2, H, W], {view id: slot}) on every rank: what pmn_fuse_view consumes directly."""
+    (buffer [world * slots, 2, H, W], {view id: slot}) on every rank: what pmn_fuse_view consumes directly.
+    ``flat`` (a scan whose views differ in size; H x W = the LARGEST view): slots are [2*H*W] floats and every view's maps are
+    packed at the start of its slot at their own size -> buffer [world * slots, 2*H*W]."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard_views(view_ids, rank, world)
     slots = (len(view_ids) + world - 1) // world
-    send = torch.zeros((slots, 2, H, W), dtype=torch.float32, device=device)
+    shape = (2 * H * W,) if flat else (2, H, W)
+    send = torch.zeros((slots,) + shape, dtype=torch.float32, device=device)
     for i, vid in enumerate(mine):
-        send[i] = local[vid].to(device=device, dtype=torch.float32)
-    if world == 1:
+        m = local[vid].to(device=device, dtype=torch.float32)
+        if flat:
+            send[i, :m.numel()] = m.reshape(-1)
+        else:
+            send[i] = m
+    if not dist.is_initialized():
         recv = send
     elif dist.get_backend() == "gloo" and send.is_cuda:  # gloo moves host memory: stage through it
-        host = torch.empty((world * slots, 2, H, W), dtype=torch.float32)
+        host = torch.empty((world * slots,) + shape, dtype=torch.float32)
         dist.all_gather_into_tensor(host, send.cpu())
         recv = host.to(device)
     else:
-        recv = torch.empty((world * slots, 2, H, W), dtype=torch.float32, device=device)
+        recv = torch.empty((world * slots,) + shape, dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(recv, send)
     slot_of = {}
     for r in range(world):

@@ -10,7 +10,7 @@ that the kernel receives exactly the matrices the reference computes (eval.py:11
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -41,22 +41,29 @@ def camera_block(K_ref: np.ndarray, E_ref: np.ndarray, srcs: Sequence[Tuple[np.n
 
 def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict], images: Dict[int, np.ndarray],
                pairs: List[Tuple[int, List[int]]], geo_pixel_thres: float, geo_depth_thres: float, geo_mask_thres: int,
-               photo_thres: float):
+               photo_thres: float, sizes: Optional[Dict[int, Tuple[int, int]]] = None):
     """Fuses the reference views listed in ``pairs`` (this rank's share of a scan).
 
-    maps [V,2,H,W] device float32 (slot_of[view id] -> slot); cams[id] = {"intrinsics" [3,3], "extrinsics" [4,4]} (numpy
+    maps [V,2,H,W] device float32 (slot_of[view id] -> slot) -- or, for a scan whose views differ in size, [V,F] flat slots with
+    ``sizes[view id] = (h, w)`` (every view's depth then confidence packed at the start of its slot; reference eval.py:203-237
+    reads every view's maps at their own size); cams[id] = {"intrinsics" [3,3], "extrinsics" [4,4]} (numpy
     float32, intrinsics already scaled to the map size); images[ref id] = [H,W,3] float in [0,1] for the reference views.
     Returns (vertices [M,3] float32, colors [M,3] uint8, masks {ref: (photo, geo, final) bool [H,W]}) in ``pairs`` order, points
     of a view in row-major pixel order -- the reference's order (eval.py:270-281)."""
     if not maps.is_cuda:
         raise PmnError("fusion runs on a ROCm GPU only (pmn_fuse_view); there is no CPU fallback")
     verts, cols, masks = [], [], {}
+    slot_sizes = None
+    if sizes is not None:
+        slot_sizes = [(1, 1)] * maps.shape[0]
+        for vid, sl in slot_of.items():
+            slot_sizes[sl] = tuple(sizes[vid])
     for ref, srcs in pairs:
         block = camera_block(cams[ref]["intrinsics"], cams[ref]["extrinsics"],
                              [(cams[s]["intrinsics"], cams[s]["extrinsics"]) for s in srcs])
         mats = torch.from_numpy(block).to(maps.device)
         m, xyz, _, _ = ops.fuse_view(maps, slot_of[ref], [slot_of[s] for s in srcs], mats, geo_pixel_thres, geo_depth_thres,
-                                     geo_mask_thres, photo_thres)
+                                     geo_mask_thres, photo_thres, sizes=slot_sizes)
         final = m[2].bool()
         verts.append(xyz[final].cpu().numpy())
         mk = m.cpu().numpy().astype(bool)
@@ -73,16 +80,19 @@ def fuse_scan(views: Dict[int, Dict], pairs: List[Tuple[int, List[int]]], geo_pi
     """Whole-scan convenience wrapper: views[id] = {depth [H,W], confidence [H,W], intrinsics, extrinsics, image [H,W,3]}
     (numpy or torch) -> (vertices, colors, masks) as ``fuse_views``; reference eval.py:193-281."""
     ids = sorted(views)
-    shapes = {tuple(np.shape(views[v]["depth"])) for v in ids}
-    if len(shapes) != 1:
-        raise PmnError(f"fusion needs all views of a scan at one size, got {sorted(shapes)}")
-    maps = torch.stack([torch.stack((torch.as_tensor(views[v]["depth"]).float(), torch.as_tensor(views[v]["confidence"]).float()))
-                        for v in ids]).to(device).contiguous()
+    sizes = {v: tuple(np.shape(views[v]["depth"])) for v in ids}
+    flat = max(2 * h * w for h, w in sizes.values())
+    maps = torch.zeros((len(ids), flat), dtype=torch.float32)
+    for i, v in enumerate(ids):  # depth then confidence, packed at the start of the view's slot
+        h, w = sizes[v]
+        maps[i, :h * w] = torch.as_tensor(views[v]["depth"]).float().reshape(-1)
+        maps[i, h * w:2 * h * w] = torch.as_tensor(views[v]["confidence"]).float().reshape(-1)
+    maps = maps.to(device)
     cams = {v: {"intrinsics": np.asarray(views[v]["intrinsics"], np.float32),
                 "extrinsics": np.asarray(views[v]["extrinsics"], np.float32)} for v in ids}
     images = {r: views[r]["image"] for r, _ in pairs}
     return fuse_views(maps, {v: i for i, v in enumerate(ids)}, cams, images, pairs, geo_pixel_thres, geo_depth_thres,
-                      geo_mask_thres, photo_thres)
+                      geo_mask_thres, photo_thres, sizes=sizes)
 
 
 def ply_records(vertices: np.ndarray, colors: np.ndarray) -> np.ndarray:

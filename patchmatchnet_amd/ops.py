@@ -573,17 +573,28 @@ def stem(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1: torch.Tensor
 
 def fuse_view(maps: torch.Tensor, ref_slot: int, src_slots: Sequence[int], mats: torch.Tensor, geo_pixel_thres: float,
               geo_depth_thres: float, geo_mask_thres: int, photo_thres: float, want_depth_avg: bool = False,
-              want_geo_sum: bool = False):
+              want_geo_sum: bool = False, sizes: Optional[Sequence[Tuple[int, int]]] = None):
     """pmn_fuse_view: consistency filtering + fusion of ONE reference view (reference eval.py:86-190, :207-281).
 
-    maps [V,2,H,W] (depth, confidence of every view of the scan, e.g. the all-gathered buffer), mats = fusion.camera_block(...)
-    (device float32).  Returns (masks [3,H,W] uint8 = photo / geo / final, xyz [H,W,3] float32 world points, depth_avg [H,W]
-    float64 or None, geo_sum [H,W] int32 or None)."""
+    maps [V,2,H,W] (depth, confidence of every view of the scan, e.g. the all-gathered buffer), or -- views of different sizes
+    -- [V,F] flat slots with ``sizes[v] = (h_v, w_v)``: slot v holds depth [h_v,w_v] then confidence [h_v,w_v] packed at its
+    start (F >= 2*h*w of the largest view).  mats = fusion.camera_block(...) (device float32).  Returns (masks [3,H,W] uint8 =
+    photo / geo / final, xyz [H,W,3] float32 world points, depth_avg [H,W] float64 or None, geo_sum [H,W] int32 or None), H x W
+    = the reference view's size."""
     _dev(maps, "maps")
     _dev(mats, "mats")
-    if maps.dim() != 4 or maps.shape[1] != 2:
-        raise PmnError("fuse_view: maps must be [V,2,H,W]")
-    V, _, H, W = maps.shape
+    if sizes is None:
+        if maps.dim() != 4 or maps.shape[1] != 2:
+            raise PmnError("fuse_view: maps must be [V,2,H,W] (or [V,F] flat slots with sizes=)")
+        V, _, H, W = maps.shape
+        stride = 2 * H * W
+        sizes = [(H, W)] * V
+    else:
+        if maps.dim() != 2 or len(sizes) != maps.shape[0]:
+            raise PmnError("fuse_view: with sizes= maps must be [V,F] flat slots and sizes must have V entries")
+        V, stride = maps.shape
+        if any(h < 1 or w < 1 or 2 * h * w > stride for h, w in sizes):
+            raise PmnError("fuse_view: a view's maps do not fit its slot")
     n = len(src_slots)
     if n > _lib.MAX_FUSE_SRC:
         raise PmnError(f"fuse_view: at most {_lib.MAX_FUSE_SRC} source views per reference view")
@@ -591,15 +602,17 @@ def fuse_view(maps: torch.Tensor, ref_slot: int, src_slots: Sequence[int], mats:
         raise PmnError("fuse_view: slot out of range")
     if mats.numel() != 48 + 64 * n:
         raise PmnError("fuse_view: mats must hold 48 + 64 * n_src floats (fusion.camera_block)")
+    H, W = sizes[ref_slot]
     slots, slots_p = _host_i32(np.asarray(list(src_slots) if n else [0], np.int32), max(n, 1), "src_slots")
+    hw, hw_p = _host_i32(np.asarray([x for s in src_slots for x in sizes[s]] if n else [0, 0], np.int32), max(2 * n, 2), "src_hw")
     masks = torch.empty((3, H, W), dtype=torch.uint8, device=maps.device)
     xyz = torch.empty((H, W, 3), dtype=torch.float32, device=maps.device)
     davg = torch.empty((H, W), dtype=torch.float64, device=maps.device) if want_depth_avg else None
     gsum = torch.empty((H, W), dtype=torch.int32, device=maps.device) if want_geo_sum else None
     with torch.cuda.device(maps.device):
-        check(_lib.lib().pmn_fuse_view(maps.data_ptr(), 2 * H * W, int(ref_slot), slots_p, n, mats.data_ptr(), H, W,
+        check(_lib.lib().pmn_fuse_view(maps.data_ptr(), int(stride), int(ref_slot), slots_p, hw_p, n, mats.data_ptr(), H, W,
                                        float(geo_pixel_thres), float(geo_depth_thres), int(geo_mask_thres), float(photo_thres),
                                        masks.data_ptr(), xyz.data_ptr(), _ptr(davg), _ptr(gsum), _stream(maps)),
               "pmn_fuse_view")
-    del slots
+    del slots, hw
     return masks, xyz, davg, gsum

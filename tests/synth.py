@@ -130,16 +130,17 @@ def scene_texture(X, Y, seed: int, n_waves: int = 40):
     return out.clamp_(0.0, 1.0)
 
 
-def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quantise: bool = True):
+def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quantise: bool = True, all_depths: bool = False):
     """Photo-consistent synthetic sample for ``synthetic_cameras(n_views, H, W)``.
 
     Returns (images: n_views x [1,3,H,W] float32 in {k/255}, intrinsics [1,N,3,3], extrinsics [1,N,4,4],
-    depth_gt [H,W] float32 = the surface's depth in the reference view (view 0))."""
+    depth_gt [H,W] float32 = the surface's depth in the reference view (view 0); with ``all_depths`` a list of the n_views
+    ground-truth depth maps, each in its own camera -- a geometrically consistent set of maps for the fusion tests)."""
     intr, extr = synthetic_cameras(n_views, H, W)
     dev = torch.device(device)
     v, u = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=dev), torch.arange(W, dtype=torch.float64, device=dev),
                           indexing="ij")
-    images, depth_gt = [], None
+    images, depth_gt, depths = [], None, []
     for i in range(n_views):
         K = torch.from_numpy(intr[0, i].astype(np.float64))
         E = torch.from_numpy(extr[0, i].astype(np.float64))
@@ -162,7 +163,10 @@ def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quan
         images.append(img.to(torch.float32)[None].contiguous())
         if i == 0:
             depth_gt = (float(Cc[2]) + s * dz).to(torch.float32)  # E_0 = I: camera depth = world z
-    return images, intr, extr, depth_gt
+        if all_depths:  # depth in camera i = third row of E_i applied to the surface point
+            Z = float(Cc[2]) + s * dz
+            depths.append((float(R[2, 0]) * X + float(R[2, 1]) * Y + float(R[2, 2]) * Z + float(t[2])).to(torch.float32))
+    return images, intr, extr, (depths if all_depths else depth_gt)
 
 
 def scene_digest(images) -> str:

@@ -13,9 +13,9 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--width", "640", "--height", "480", "--steps", "6", "--warmup", "2", "--samples", "3", "--roofline-steps", "4",
-         "--no-cpu-baseline"]
+         "--no-cpu-baseline", "--steady-seconds", "0.2"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-        "dtype", "data", "config", "roofline", "single_stream_eager"}
+        "dtype", "data", "config", "roofline", "single_stream_eager", "steady_state"}
 
 
 def _line(out: str) -> dict:
@@ -31,6 +31,8 @@ def _check(line: dict, n_gpus: int) -> None:
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["launches"] == 5 * r["steps_with_events"]  # five pmn_warp_correlate launches per depth map
+    assert r["tap_bytes_per_step"] > r["alg_bytes_per_step"] and 0 < r["l1_frac"] < 1
+    assert line["steady_state"]["steps"] >= line["steps"] and line["steady_state"]["value"] > 0
 
 
 def test_bench_line_default_and_eager():
@@ -59,3 +61,31 @@ def test_bench_two_ranks_on_one_gpu():
     _check(line, 2)
     assert "{" not in outs[1][0]  # only rank 0 prints
     assert line["config"]["in_flight"] == 3 and line["scaling"] == "weak"
+
+
+def test_bench_one_rank_over_rccl():
+    """The product's collective backend, for real: launched the torch.distributed.run way with WORLD_SIZE=1, bench.py initialises
+    backend "nccl" (= RCCL) with device_id=, and its barrier / all_reduce / closing all_gather_into_tensor run on device memory
+    through librccl -- the same calls eight ranks make."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29800 + os.getpid() % 1000))
+    env.pop("PMN_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    _check(_line(p.stdout), 1)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher (the form of the driver's N=1 command) spawns the two ranks itself and rank 0
+    prints the single line; gloo because this box has one GPU."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PMN_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _line(p.stdout)
+    _check(line, 2)
+    assert line["scaling"] == "weak"

@@ -110,6 +110,33 @@ def test_hip_graph_replay_writes_the_same_bytes(tmp_path):
     assert np.isfinite(d).all() and d.min() > 300
 
 
+def test_samples_in_flight_draw_their_own_noise(tmp_path):
+    """--in_flight 3 against --in_flight 1 at a size where the GPU, not the host, is the bottleneck (slots really overlap): every
+    map byte-identical with --sample_seed.  The stage-3 draw of a replayed forward is made eagerly per slot (graph.py); a Philox
+    kernel captured INSIDE the graphs would share one seed / offset pair between all slots and a slot could draw with its
+    neighbour's offset."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    sys.path.insert(0, ROOT)
+    import eval as pm_eval
+    data = str(tmp_path / "data")
+    synth.write_scan(data, "scanF", n_views=7, H=576, W=768, n_src=4)
+    with open(os.path.join(data, "list.txt"), "w") as f:
+        f.write("scanF\n")
+    ckpt = os.path.join(GU.GOLDEN_DIR, "params_000007.npz")
+    outs = {}
+    for flight in ("1", "3"):
+        out = str(tmp_path / ("out_f" + flight))
+        pm_eval.main(["--input_folder", data, "--output_folder", out, "--checkpoint_path", ckpt, "--scan_list",
+                      os.path.join(data, "list.txt"), "--num_views", "4", "--output_type", "depth", "--num_workers", "0",
+                      "--sample_seed", "7", "--hip_graph", "1", "--in_flight", flight])
+        outs[flight] = out
+    for v in range(7):
+        for kind in ("depth_est", "confidence"):
+            a = open(os.path.join(outs["1"], "scanF", kind, "{:0>8}.pfm".format(v)), "rb").read()
+            b = open(os.path.join(outs["3"], "scanF", kind, "{:0>8}.pfm".format(v)), "rb").read()
+            assert a == b, (kind, v)
+
+
 def _run_eval(cmd_args, env_extra, cwd):
     import subprocess
     env = dict(os.environ)

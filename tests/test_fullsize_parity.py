@@ -86,14 +86,15 @@ def _index_check(got_idx, got_score, want_idx):
     return frac
 
 
-def test_cfg2_chained_cascade_from_hip_featurenet():
-    """bench.py's sample: HIP FeatureNet features -> the whole HIP cascade vs oracle.cascade-style chaining on the same features."""
+@pytest.mark.parametrize("scene,H,W,nsrc", [("surface", 1200, 1600, 5), ("rolled", 1200, 1600, 5), ("surface", 1056, 1920, 7)])
+def test_chained_cascade_from_hip_featurenet(scene, H, W, nsrc):
+    """bench.py's samples (cfg-2 on both scenes; cfg-3 = 1920x1056, N=7): HIP FeatureNet features -> the whole HIP cascade vs
+    oracle.cascade-style chaining on the same features."""
     P = _gpu()
     import bench
     model, params, kw = _model(P)
     cfgs = _configs(kw)
-    H, W, nsrc = 1200, 1600, 5
-    s = bench.make_samples(1, nsrc + 1, H, W, torch.device(DEV), 0)[0]
+    s = bench.make_samples(1, nsrc + 1, H, W, torch.device(DEV), 0, scene)[0]
     noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(1234)).to(DEV)
     dbg = {}
     with torch.no_grad():
@@ -168,11 +169,71 @@ def test_cfg2_chained_cascade_from_hip_featurenet():
     _, idx_hip = P.ops.confidence(score_hip.contiguous(), H, W, want_index=True)
     _, idx_or = O.confidence(oscore, (H, W))
     worst["depth_index_mismatch_frac"] = _index_check(n(idx_hip), n(score_hip), idx_or)
-    _report(test="cfg2_chained_cascade", **worst)
+    _report(test="chained_cascade", scene=scene, H=H, W=W, n_src=nsrc, **worst)
+
+
+def test_cfg2_scene_end_to_end_against_the_reference_itself():
+    """BASELINE configs[1] (1600x1200, N=5, iters 1,2,2), FREE-RUNNING from the images, against the REFERENCE's own output
+    (tests/golden/cfg2_scene.npz: the imported reference run by tests/golden/make_golden.py on the photo-consistent scene of
+    tests/synth.render_scene; reference models/net.py:176-301).  Nothing is teacher-forced: HIP FeatureNet -> HIP cascade -> HIP
+    refinement vs the reference's CPU forward.
+
+    Gates.  The reference does not reproduce ITSELF to 1e-3 on every pixel: profiles/r03_noise_floor.json (scripts/noise_floor.py)
+    has, on this scene, 4.6e-5 of the final-depth pixels beyond 1e-3 between 8 and 1 threads and 2.3e-4 between oneDNN and native
+    convolutions (max 4.6e-3 / 9.1e-3; p99 2e-7), because a rounding-level change of a feature occasionally moves the soft arg-max
+    of one pixel to a neighbouring hypothesis and later stages keep it.  So: the BULK must agree far inside the north star's 1e-3
+    (p99 <= 1e-5), and the exceptional pixels must be no more frequent than a small multiple of the reference's own floor
+    (<= 1e-3 of the pixels beyond 1e-3, none beyond 5e-2)."""
+    P = _gpu()
+    model, params, kw = _model(P)
+    g = GU.load_npz("cfg2_scene.npz")
+    H, W, nv = int(g["H"]), int(g["W"]), int(g["n_views"])
+    imgs, intr, extr, gt = synth.render_scene(nv, H, W, int(g["scene_seed"]))
+    assert synth.scene_digest(imgs) == str(g["scene_digest"]), "this host renders a different scene than the golden was made on"
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(int(g["noise_seed"]))).to(DEV)
+    dbg = {}
+    with torch.no_grad():
+        depth, conf, dpm = model([im.to(DEV) for im in imgs], t(intr), t(extr), torch.tensor([425.0], device=DEV),
+                                 torch.tensor([935.0], device=DEV), noise=noise, debug=dbg)
+    torch.cuda.synchronize()
+    rep = {}
+
+    def stats(name, got, want):
+        rel = np.abs(got.astype(np.float64) - want) / np.abs(want)
+        rep[name] = {"max": float(rel.max()), "p999": float(np.quantile(rel, 0.999)), "p99": float(np.quantile(rel, 0.99)),
+                     "frac_over_1e-3": float((rel > 1e-3).mean()), "frac_over_1e-4": float((rel > 1e-4).mean())}
+        return rep[name]
+
+    for st in (3, 2, 1):
+        for it, d in enumerate(dpm[st]):
+            stats(f"s{st}_it{it + 1}", n(d), g[f"s{st}_it{it + 1}_depth_out"])
+    fin = stats("final", n(depth), g["depth"])
+    err_gt = np.abs(n(depth)[0, 0] - gt.numpy())
+    rep["vs_ground_truth_mm"] = {"median": float(np.median(err_gt)), "p90": float(np.quantile(err_gt, 0.9))}
+    # stage-3 view weights (PixelwiseNet max over D): the first free-running product of the cascade
+    rep["view_weights_abs_max"] = GU.abs_err(n(dbg[3][0]["view_weights"]), g["view_weights"])
+    # confidence: reads the stage-1 probabilities at the integer index trunc(sum_d d p_d)
+    cdiff = np.abs(n(conf) - g["confidence"])
+    rep["confidence_frac_over_1e-3"] = float((cdiff > 1e-3).mean())
+    score_hip = dbg[1][-1]["score"]
+    _, idx_hip = P.ops.confidence(score_hip.contiguous(), H, W, want_index=True)
+    idx_bad = n(idx_hip).astype(np.int64) != g["depth_index"].astype(np.int64)
+    rep["depth_index_mismatch_frac"] = float(idx_bad.mean())
+    _report(test="cfg2_scene_vs_reference", **rep)
+    # the stage-3 first iteration has no history to amplify: strict
+    assert rep["s3_it1"]["max"] < 1e-4, rep["s3_it1"]
+    assert rep["view_weights_abs_max"] < 1e-4, rep["view_weights_abs_max"]
+    for k in ("s3_it2", "s2_it1", "s2_it2", "s1_it1", "final"):
+        assert rep[k]["p99"] < 1e-5, (k, rep[k])
+        assert rep[k]["frac_over_1e-3"] < 1e-3, (k, rep[k])
+        assert rep[k]["max"] < 5e-2, (k, rep[k])
+    assert fin["p999"] < 1e-3, fin
+    assert rep["vs_ground_truth_mm"]["median"] < 1.0, rep["vs_ground_truth_mm"]  # the reference itself: 0.63 mm
+    assert rep["depth_index_mismatch_frac"] < 2e-3 and rep["confidence_frac_over_1e-3"] < 5e-3, rep
 
 
 @pytest.mark.parametrize("stage,n_src,H,W", [(3, 7, 1056, 1920), (2, 7, 1056, 1920), (1, 7, 1056, 1920),
-                                             (2, 5, 1200, 1600), (3, 10, 2048, 3072), (1, 10, 2048, 3072)])
+                                             (2, 5, 1200, 1600), (3, 10, 2048, 3072), (2, 10, 2048, 3072), (1, 10, 2048, 3072)])
 def test_fullsize_stage_against_oracle_cfg3_cfg5(stage, n_src, H, W):
     """One PatchMatch stage at cfg-3 / cfg-5 sizes (and the cfg-2 stage the round-1 suite skipped) vs the CPU oracle on identical
     inputs (same conv offsets)."""

@@ -84,3 +84,46 @@ def test_fuse_scan_product_wrapper_and_ply(tmp_path):
     assert agree > 0.998
     fusion.write_ply(str(tmp_path / "f.ply"), v, c)
     assert (tmp_path / "f.ply").stat().st_size == len(fusion.ply_header(len(v))) + 15 * len(v)
+
+
+def _consistent_scene(V, H, W, sizes=None, seed=0):
+    """Geometrically CONSISTENT maps: every view's ground-truth depth of the analytic surface of synth.render_scene in its own
+    camera (+ 0.02 mm noise), so that the >= geo_mask_thres branch of the reference's filter (eval.py:248-252) holds on nearly every
+    pixel that the source views see -- by construction, not by luck of a noise level.  ``sizes[v]`` = (h, w) re-renders view v at
+    its own size with its intrinsics scaled (eval.py:214-229: per-view image size after --image_max_dim)."""
+    rng = np.random.default_rng(seed)
+    views = {}
+    for v in range(V):
+        h, w = (H, W) if sizes is None else sizes[v]
+        imgs, intr, extr, depths = synth.render_scene(V, h, w, seed=seed, all_depths=True)
+        d = depths[v].numpy() + rng.standard_normal((h, w)).astype(np.float32) * 0.02
+        c = (0.4 + 0.6 * rng.random((h, w))).astype(np.float32)
+        views[v * 2 + 3] = dict(depth=d.astype(np.float32), confidence=c, intrinsics=intr[0, v].astype(np.float32),
+                                extrinsics=extr[0, v].astype(np.float32), image=imgs[v][0].permute(1, 2, 0).numpy())
+    return views
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_fuse_scan_on_a_consistent_scene_incl_mixed_view_sizes(mixed):
+    """pmn_fuse_view through fusion.fuse_scan vs the fusion oracle on a scene whose maps ARE consistent; ``mixed``: every view at
+    its own size (reference eval.py:203-237 reads each view's maps at their own size -- round 2 raised on such scans)."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    from patchmatchnet_amd import fusion
+    V, H, W = 5, 120, 160
+    sizes = [(120, 160), (96, 128), (120, 160), (144, 192), (90, 120)] if mixed else None
+    views = _consistent_scene(V, H, W, sizes)
+    ids = sorted(views)
+    pairs = [(r, [s for s in ids if s != r]) for r in ids]
+    thr = (1.0, 0.01, 3, 0.5)
+    v, c, masks = fusion.fuse_scan(views, pairs, *thr, torch.device(DEV))
+    vo, co, mo = FO.fuse_scan(views, pairs, *thr)
+    for r in ids:
+        assert masks[r][2].shape == views[r]["depth"].shape
+        np.testing.assert_array_equal(masks[r][0], mo[r][0])  # photometric mask: a plain comparison
+        assert float(np.mean(masks[r][1] != mo[r][1])) < 2e-3  # geometric mask: equal off threshold ties
+        assert mo[r][1].mean() > 0.5, (r, mo[r][1].mean())    # ... and it is genuinely ON for most of the view
+    assert abs(len(v) - len(vo)) <= 0.002 * len(vo) + 2
+    same = all(np.array_equal(masks[r][2], mo[r][2]) for r in ids)
+    if same:
+        assert np.abs(v - vo).max() / np.abs(vo).max() < 1e-6
+        np.testing.assert_array_equal(c, co)
