@@ -12,29 +12,42 @@ import numpy as np
 from PIL import Image
 
 
+def _linear_taps(dst: int, src: int):
+    """Source index pairs and float32 weights of OpenCV's resize(INTER_LINEAR) along one axis (imgproc/src/resize.cpp,
+    cv::resize -> the generic ResizeFunc set-up): scale = src / dst in double; fx = (float)((d + 0.5) * scale - 0.5);
+    s = floor(fx); fx -= s; s < 0 -> (s, fx) = (0, 0); s >= src - 1 -> (s, fx) = (src - 1, 0); weights (1 - fx, fx) in float32."""
+    scale = float(src) / float(dst)
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s0 = np.floor(f).astype(np.int64)
+    f = (f - s0.astype(np.float32)).astype(np.float32)
+    lo = s0 < 0
+    f[lo], s0[lo] = 0.0, 0
+    hi = s0 >= src - 1
+    f[hi], s0[hi] = 0.0, src - 1
+    s1 = np.minimum(s0 + 1, src - 1)
+    return s0, s1, (np.float32(1.0) - f).astype(np.float32), f
+
+
 def resize_bilinear(image: np.ndarray, height: int, width: int) -> np.ndarray:
-    """Plain bilinear resize with half-pixel centres and no anti-aliasing (what cv2.INTER_LINEAR computes on float
-    images, reference data_io.py:26-29).  image [H,W] or [H,W,C] float32."""
+    """cv2.resize(image, (width, height), interpolation=cv2.INTER_LINEAR) on a float32 image (reference data_io.py:26-29),
+    restated from OpenCV 4.x (no OpenCV in this image; opencv-python is unpinned in the reference's requirements): half-pixel
+    centres, no anti-aliasing, coordinates and weights in float32 as ``_linear_taps`` documents, the horizontal pass first
+    (row[x] = S[x0]*a0 + S[x1]*a1), then the vertical one (dst = row0*b0 + row1*b1), every product and sum rounded to float32.
+    PARITY WITH cv2 ITSELF IS UNPINNED: OpenCV's AVX2 / NEON builds fuse the vertical pass into an FMA, which can differ in the
+    last bit; tests/test_reference_io.py pins this function to a hand-computed vector and to the reference's own read_image /
+    MVSDataset flow around it.  image [H,W] or [H,W,C] float32."""
     H, W = image.shape[:2]
-    ys = (np.arange(height, dtype=np.float64) + 0.5) * (H / height) - 0.5
-    xs = (np.arange(width, dtype=np.float64) + 0.5) * (W / width) - 0.5
-    ys = np.clip(ys, 0, H - 1)
-    xs = np.clip(xs, 0, W - 1)
-    y0 = np.floor(ys).astype(np.int64)
-    x0 = np.floor(xs).astype(np.int64)
-    y1 = np.minimum(y0 + 1, H - 1)
-    x1 = np.minimum(x0 + 1, W - 1)
-    fy = (ys - y0).astype(np.float32)
-    fx = (xs - x0).astype(np.float32)
+    image = np.asarray(image, np.float32)
+    y0, y1, b0, b1 = _linear_taps(height, H)
+    x0, x1, a0, a1 = _linear_taps(width, W)
     if image.ndim == 3:
-        fy = fy[:, None, None]
-        fx = fx[None, :, None]
+        a0, a1, b0, b1 = a0[None, :, None], a1[None, :, None], b0[:, None, None], b1[:, None, None]
     else:
-        fy = fy[:, None]
-        fx = fx[None, :]
-    top = image[y0][:, x0] * (1 - fx) + image[y0][:, x1] * fx
-    bot = image[y1][:, x0] * (1 - fx) + image[y1][:, x1] * fx
-    return (top * (1 - fy) + bot * fy).astype(np.float32)
+        a0, a1, b0, b1 = a0[None, :], a1[None, :], b0[:, None], b1[:, None]
+    rows0, rows1 = image[y0], image[y1]
+    top = rows0[:, x0] * a0 + rows0[:, x1] * a1
+    bot = rows1[:, x0] * a0 + rows1[:, x1] * a1
+    return (top * b0 + bot * b1).astype(np.float32)
 
 
 def scale_to_max_dim(image: np.ndarray, max_dim: int) -> Tuple[np.ndarray, int, int]:
