@@ -31,7 +31,7 @@ from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
 from patchmatchnet_amd.graph import GraphedForward
 from patchmatchnet_amd.data_io import image_shape, read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
-from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
+from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset, MVSViewListDataset
 
 
 def print_args(args) -> None:
@@ -209,10 +209,12 @@ def save_depth(args, rank, world, device, on_scan_done=None):
     rank holds one scan's maps at a time instead of the whole dataset's).
 
     Per-scan feature cache: every image of a scan is a source view of ~num_views other samples,
-    and the reference decodes AND re-encodes it each time.  With --feature_cache > 0 a (scan, light) group is processed in two
-    passes: every view the rank's samples read is decoded once and pushed through FeatureNet once (its pyramid, 53 MB per
-    1600x1200 view, stays on the device, channels-last); then the samples are run from their cameras alone.  Same maps, bit for
-    bit, as the plain path (tests/test_eval_gpu.py)."""
+    and the reference decodes AND re-encodes it each time.  With --feature_cache > 0 every view the rank's samples read is decoded
+    once and pushed through FeatureNet once (its pyramid, 53 MB per 1600x1200 view, stays on the device, channels-last) and the
+    samples run from their cameras alone.  --stream_views 1 (default): ONE DataLoader over all views of all groups, in the order
+    the samples first need them -- the decode workers live across scans, a sample runs as soon as ITS views are encoded (decode
+    overlaps the forwards), and a pyramid is dropped after its last use; --stream_views 0: round 2's two passes per group (decode
+    + encode everything, then the samples).  Same maps, bit for bit, as the plain path (tests/test_eval_gpu.py)."""
     model = load_model(args, device)
     # --hip_graph: one HIP-graph replay per sample instead of ~55 Python-issued launches -- the launch thread is what the
     # uploads and the writer threads compete with; --in_flight S: S samples in flight, each on its own HIP stream with its own
@@ -258,10 +260,77 @@ def save_depth(args, rank, world, device, on_scan_done=None):
             for key in [k for k in produced if k[0] == scan]:
                 del produced[key]
 
+    # ---- streaming encode-once plan: which groups qualify, their views in first-use order, one loader for all of them ----------
+    group_list = [(scan, light, indices) for scan in dataset.scans for light, indices in by_scan.get(scan, [])]
+    eligible, view_items = {}, []
+    for gi, (scan, light, indices) in enumerate(group_list):
+        ok = args.feature_cache > 0 and args.batch_size == 1 and _encode_once_ok(dataset, scan, light, dataset.views_of(indices))
+        eligible[(scan, light)] = ok
+        if ok and args.stream_views:
+            seen = set()
+            for i in indices:
+                _, _, ref, src = dataset.metas[i]
+                for v in [ref] + src[:min(len(src), dataset.num_views)]:
+                    if v not in seen:
+                        seen.add(v)
+                        view_items.append((gi, scan, light, v))
+    view_stream = None
+    if view_items:
+        vds = MVSViewListDataset(dataset, view_items)
+        kw = dict(prefetch_factor=2, persistent_workers=True) if args.num_workers > 0 else {}
+        vloader_all = DataLoader(vds, batch_sampler=vds.batches(4), num_workers=args.num_workers, pin_memory=True, **kw)
+        view_stream = iter(DevicePrefetcher(vloader_all, device, keys=("image",)))
+
+    def run_group_streaming(gi, scan, light, indices):
+        """Samples of one group from cameras only; views are pulled from the shared decode stream as the samples need them."""
+        nonlocal done
+        last_use = {}
+        for k, i in enumerate(indices):
+            _, _, ref, src = dataset.metas[i]
+            for v in [ref] + src[:min(len(src), dataset.num_views)]:
+                last_use[v] = k
+        refs = {dataset.metas[i][2] for i in indices}
+        pyramids, images = {}, {}
+        dataset.load_images = False
+        loader = DataLoader(torch.utils.data.Subset(dataset, indices), batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+        t_group, n_enc = time.time(), 0
+        for k, sample in enumerate(loader):
+            start = time.time()
+            ids = [int(v) for v in sample["view_ids"][0]]
+            while any(v not in pyramids for v in ids):  # decode stream order = first-use order: the next batches hold them
+                batch = next(view_stream)
+                assert int(batch["group"][0]) == gi, "view stream out of step with the sample order"
+                imgs = batch["image"]
+                f = model.feature.forward_hip(imgs)
+                for j, v in enumerate(batch["view"].tolist()):
+                    pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
+                    if v in refs:
+                        images[v] = imgs[j:j + 1]  # Refinement reads the reference image
+                    n_enc += 1
+            ref_img = images[ids[0]]
+            _seed_sample(args, dataset, sample)
+            cams = [sample[key].to(device) for key in ("intrinsics", "extrinsics", "depth_min", "depth_max")]
+            feats = [pyramids[v] for v in ids]
+            held = cams + [ref_img] + [t for f in feats for t in f.values()]  # the slot's stream reads these after we let go
+            st, (depth, confidence) = run_sample(held, [ref_img] * len(ids), *cams, features=feats)
+            with torch.cuda.stream(st):
+                _write_maps(args, sample, depth, confidence, produced, writer)
+            for v in ids:  # pyramids past their last use leave the device (record_stream above keeps them until the slot is done)
+                if last_use[v] == k:
+                    pyramids.pop(v, None)
+                    images.pop(v, None)
+            done += 1
+            print("Iter {}/{}, time = {:.3f}".format(done, total, time.time() - start))
+        dataset.load_images = True
+        print("{}{}: {} views encoded once, {} samples, time = {:.3f}".format(scan, "/" + light if light else "", n_enc,
+                                                                             len(indices), time.time() - t_group))
+
     def run_group(scan, light, indices):
         nonlocal done
         views = dataset.views_of(indices)
-        encode_once = args.feature_cache > 0 and args.batch_size == 1 and _encode_once_ok(dataset, scan, light, views)
+        encode_once = eligible[(scan, light)]
+        if encode_once and view_stream is not None:
+            return run_group_streaming(group_list.index((scan, light, indices)), scan, light, indices)
         subset = torch.utils.data.Subset(dataset, indices)
         if not encode_once:
             dataset.load_images = True
@@ -455,6 +524,9 @@ def build_parser():
                    help="samples in flight per GPU (HIP streams, one graph-replay slot each); needs --hip_graph 1")
     p.add_argument("--hip_graph", type=int, default=1,
                    help="1: replay the forward as a HIP graph (one launch per sample); 0: issue every kernel from Python")
+    p.add_argument("--stream_views", type=int, default=1,
+                   help="1: with --feature_cache, decode every view once through ONE DataLoader over all scans, in first-use order, "
+                        "overlapped with the forwards; 0: two passes per scan (decode + encode all views, then the samples)")
     p.add_argument("--feature_cache", type=int, default=64,
                    help="> 0: decode and encode every view of a scan ONCE per rank and keep its FeatureNet pyramid on the device "
                         "(0 = re-decode and re-encode per sample like the reference; needs --batch_size 1)")

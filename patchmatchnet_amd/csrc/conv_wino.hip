@@ -38,7 +38,14 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const float* __restri
                                                                              float* __restrict__ out, const WinoArgs a) {
     static_assert(C == 32 || C == 64, "16 channels: conv_wino16_kernel");
     constexpr int NCB = C / 16, TG = (C == 64 ? 2 : 1), NTHR = 256;
-    constexpr int CCP = 20, PH = 10, PW = 18, VP = 16, NT = 32;  // patch pitch 20 words / pixel; V pitch 16 words / tile
+    // LDS banking (ds_read_b128 / ds_write_b128: a 256-B bank row = 16 slots of 16 B; a read is served in four fixed 16-lane
+    // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32; MI355X_MICROARCH.md, LDS): round 2 measured 39-42 % of this kernel's LDS
+    // cycles as bank conflicts.  (a) patch pitch 24 words (6 slots) per pixel: the transform phase's lanes (tile = tid >> 2,
+    // quad = tid & 3) of one group cover four tiles {0,3,5,6} / {1,2,4,7} two pixels apart -> base slots 12 tx mod 16 =
+    // {0,4,12,8} / {12,8,0,4}: conflict-free (pitch 20: 10 tx mod 16 = {0,14,2,12}: two-way).  (b) V keeps 16 words (4 slots)
+    // per tile, but a tile's four channel quads are stored at sub-slot quad ^ 2*((tile >> 3) & 1): the MFMA phase's groups hold
+    // tiles j in {0-3,12-15} with one k-quad and j in {4-11} with the next, and 4 j mod 16 alone puts j and j + 4 on one slot.
+    constexpr int CCP = 24, PH = 10, PW = 18, VP = 16, NT = 32;
     __shared__ float4 P4[PH * PW * CCP / 4];
     __shared__ float4 V4[16 * NT * VP / 4];
     float* P = reinterpret_cast<float*>(P4);
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const float* __restri
                 w[2][b] = f4sub(d2, d1);
                 w[3][b] = f4sub(d1, d3);
             }
-            float* vp = V + t * VP + 4 * c4;
+            float* vp = V + t * VP + 4 * (c4 ^ (2 * ((t >> 3) & 1)));
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 *reinterpret_cast<float4*>(vp + ((4 * p + 0) * NT) * VP) = f4sub(w[p][0], w[p][2]);
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const float* __restri
         // (3) 16 positions: M_pos = V_pos . U_pos over this chunk's 16 input channels, folded into Y with the inverse-transform
         // coefficient of the position.  Two positions at a time (independent MFMA chains: the 16x16x4 result latency is 40 cycles
         // against a 32-cycle issue); sched_barriers keep the B ring reloads behind the MFMAs that read the slot.
-        const float* va = V + (g0 * 16 + j) * VP + 4 * kq;
+        const float* va = V + (g0 * 16 + j) * VP + 4 * (kq ^ (2 * (j >> 3)));
 #pragma unroll
         for (int pos = 0; pos < 16; pos += 2) {
             f32x4 M[2][TG];
@@ -182,6 +189,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const float* __restri
 // kernel (32 KB of LDS per 32 tiles: 6 waves per CU, transforms and barriers dominating the few MFMAs) is dropped: lane (tile i,
 // channel quad kq) reads the 16 patch values of ITS operand (16 ds_read_b128), transforms them in registers and feeds the 64
 // MFMAs of its wave directly.  Workgroup = 4 waves x 16 tiles (16 x 16 pixels), LDS = the 18 x 18 patch only (26 KB).
+__device__ __forceinline__ constexpr int wino16_tile_row(int j) { return (j >= 4 && j < 12) ? 1 : 0; }
+__device__ __forceinline__ constexpr int wino16_tile_col(int j) { return (j >= 4 && j < 12) ? j - 4 : (j < 4 ? j : j - 8); }
+
 __global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __restrict__ in, const float4* __restrict__ wU,
                                                             const float* __restrict__ shift, float* __restrict__ out,
                                                             const WinoArgs a) {
@@ -216,8 +226,13 @@ __global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __rest
     }
     __syncthreads();
 
-    // this lane's A operands: tile t = 16 wave + j (tile row 2 wave + (j >> 3), column j & 7), channels [4 kq, +4), all 16 positions
-    const int ty = 2 * wave + (j >> 3), tx = j & 7;
+    // this lane's A operands: one of the wave's 16 tiles (2 rows x 8 columns), channels [4 kq, +4), all 16 positions.  Which tile
+    // MFMA row j stands for is free, and it decides the LDS bank conflicts: a ds_read_b128 is served in the lane groups
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), i.e. rows j in {0-3,12-15} with quad kq and j in {4-11} with quad kq + 1.  The slot
+    // (16 B) of a tile is 180 trow + 10 tcol + kq mod 16 = an even number that takes all 8 even values along a tile row, and the
+    // SAME 8 values in the other row -- so rows {0-3,12-15} take tile row 0 and rows {4-11} tile row 1: 16 distinct slots per
+    // group (round 2's j -> (j >> 3, j & 7) put j and j + 4 ... on one slot: 48 % of the LDS cycles were conflicts).
+    const int ty = 2 * wave + wino16_tile_row(j), tx = wino16_tile_col(j);
     const float* pp = P + ((2 * ty) * PW + 2 * tx) * CCP + 4 * kq;
     float4 V[4][4];
 #pragma unroll
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __rest
     const float sh = shift[j];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int t = kq * 4 + r, oty = 2 * wave + (t >> 3), otx = t & 7;  // D rows = tiles 4 kq + r of this wave's 16
+        const int t = kq * 4 + r, oty = 2 * wave + wino16_tile_row(t), otx = wino16_tile_col(t);  // D row t = MFMA row t's tile
 #pragma unroll
         for (int oa = 0; oa < 2; ++oa)
 #pragma unroll
@@ -364,6 +379,12 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
     // flattens the chunk loop, hoists all 49 weight loads to the top and spills
     constexpr int NCB = COUT / 16, NG = 4 / NCB;                      // cout blocks, tile groups per workgroup
     constexpr int PH = 8 * NG + 3, PW = 35, PP = 10;                  // patch rows / cols / words per pixel (8 channels + 2 pad)
+    // Row pitch RP = PW * PP + 4 words, and the pixels of patch row y are shifted by 4 * ((y >> 2) & 1) words.  A ds_read_b64 is
+    // served in the two 32-lane halves {tile j = 0..15} x {kq, kq + 1}; the lane's word is 4 RP trow + 40 tcol + 2 kq, 40 tcol mod 64
+    // runs through the 8 multiples of 8 and 4 RP = 8 mod 64 -- so without the shift tile rows 0 and 1 (4 patch rows apart) sit on
+    // the SAME 8 bank groups and every read is a two-way conflict (round 2: 70-72 % of this kernel's LDS cycles).  Patch rows 4
+    // apart always differ in (y >> 2) & 1, so one of the two tile rows is shifted by half a bank group: 64 distinct banks.
+    constexpr int RP = PW * PP + 4;
     constexpr int NPOS = 49, RING = 7, NTHR = 256;  // 49 % RING == 0: a position keeps its ring slot from chunk to chunk
     extern __shared__ float4 w5_lds4[];
     float* P = reinterpret_cast<float*>(w5_lds4);
@@ -385,7 +406,8 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
 
     // this lane's tile inside the group: 2 x 8 tiles, 4 input pixels apart; patch rows of the group start at 8 g
     const int ty = j >> 3, tx = j & 7;
-    const float* pl = P + ((8 * g + 4 * ty) * PW + 4 * tx) * PP + 2 * kq;
+    const float* pl = P + (8 * g + 4 * ty) * RP + 4 * tx * PP + 2 * kq;
+    const int sw_lo = 4 * ty, sw_hi = 4 - 4 * ty;  // shift of this tile's patch rows 0..3 / 4..6 (rows 8 g + 4 ty + [0, 7))
 
 #pragma unroll 1
     for (int cc = 0; cc < nch; ++cc) {
@@ -407,8 +429,10 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
                 for (int k = 0; k < SB; ++k) {
                     const int idx = tid + (k0 + k) * NTHR, pix = idx >> 1, q = idx & 1;
                     if (k0 + k < NL && idx < TOT) {  // pixel pitch 10 words: 8-byte aligned only
-                        *reinterpret_cast<f32x2*>(P + pix * PP + 4 * q) = f32x2{v[k].x, v[k].y};
-                        *reinterpret_cast<f32x2*>(P + pix * PP + 4 * q + 2) = f32x2{v[k].z, v[k].w};
+                        const int py = pix / PW, px = pix - py * PW;
+                        float* dst = P + py * RP + px * PP + 4 * ((py >> 2) & 1) + 4 * q;
+                        *reinterpret_cast<f32x2*>(dst) = f32x2{v[k].x, v[k].y};
+                        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[k].z, v[k].w};
                     }
                 }
             }
@@ -430,7 +454,9 @@ __global__ __launch_bounds__(256, 3) void conv5x5s2_wino_kernel(const float* __r
 #pragma unroll
                     for (int ib = 0; ib < 4; ++ib) {
                         d[ia][ib] = f32x2{0.f, 0.f};
-                        if (ia < nr && ib < ns) d[ia][ib] = *reinterpret_cast<const f32x2*>(pl + ((r + 2 * ia) * PW + s + 2 * ib) * PP);
+                        if (ia < nr && ib < ns)
+                            d[ia][ib] = *reinterpret_cast<const f32x2*>(pl + (r + 2 * ia) * RP + (s + 2 * ib) * PP +
+                                                                        ((r + 2 * ia) >= 4 ? sw_hi : sw_lo));
                     }
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
@@ -496,7 +522,7 @@ template <int CIN, int COUT>
 static int launch_w5(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
     constexpr int NG = 4 / (COUT / 16);
     const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
-    const size_t lds = (size_t)(8 * NG + 3) * 35 * 10 * sizeof(float);
+    const size_t lds = (size_t)(8 * NG + 3) * (35 * 10 + 4) * sizeof(float);  // PH rows of RP words (kernel constants)
     auto kern = conv5x5s2_wino_kernel<CIN, COUT>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((Wo + 15) / 16) * ((Ho + 4 * NG - 1) / (4 * NG));

@@ -1,24 +1,66 @@
 #!/usr/bin/env python
-"""eval.py on a generated 1600x1200 scan (16 views, 5 source views each): plain path vs encode-once path, wall time of the
-depth stage (decode + forward + PFM write).  Development aid; everything lives under a temp dir."""
-import os, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import synth
-import eval as pm_eval
+"""eval.py END TO END with the JPEG decode in: a generated DTU-layout scan of the photo-consistent
+scene (tests/synth.write_scene_scan: 49 views, 1600x1200, JPEG quality 95, on tmpfs), eval.py --num_views 5 --output_type depth
+(decode -> upload -> FeatureNet once per view -> cascade -> refinement -> download -> PFM files), feature cache on, swept over the
+number of decode workers and the two encode-once schedules (--stream_views 1: one persistent decode stream overlapped with the
+forwards; 0: round 2's two passes per scan).  Prints depth-maps/s per configuration = samples / wall time of eval.main()
+(model load and graph capture included in the first, excluded by a warm-up run before the sweep).
 
-n_views = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-with tempfile.TemporaryDirectory() as tmp:
-    data = os.path.join(tmp, "data")
-    synth.write_scan(data, "scan1", n_views=n_views, H=1200, W=1600, n_src=5)
-    with open(os.path.join(data, "list.txt"), "w") as f:
-        f.write("scan1\n")
-    ckpt = os.path.join(ROOT, "tests", "golden", "params_000007.npz")
-    for cache in ("0", "64", "0", "64"):
-        out = os.path.join(tmp, "out" + cache)
-        t = time.time()
-        pm_eval.main(["--input_folder", data, "--output_folder", out, "--checkpoint_path", ckpt, "--scan_list",
-                      os.path.join(data, "list.txt"), "--num_views", "5", "--output_type", "depth", "--num_workers", os.environ.get("EVAL_WORKERS", "0"),
-                      "--feature_cache", cache, "--file_format", ".pfm"])
-        dt = time.time() - t
-        print(f"RESULT feature_cache={cache}: {dt:.2f} s for {n_views} samples -> {n_views / dt:.1f} samples/s", flush=True)
+    python scripts/eval_bench.py [n_scans=2] [n_views=49]
+"""
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+import eval as pm_eval  # noqa: E402
+
+n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+n_views = int(sys.argv[2]) if len(sys.argv) > 2 else 49
+base = "/dev/shm/pmn_eval_bench" if os.path.isdir("/dev/shm") else "/tmp/pmn_eval_bench"
+shutil.rmtree(base, ignore_errors=True)
+data = os.path.join(base, "data")
+t0 = time.time()
+for s in range(n_scans):
+    synth.write_scene_scan(data, "scan%d" % (s + 1), n_views, 1200, 1600, n_src=10, seed=s, device="cuda")
+with open(os.path.join(data, "list.txt"), "w") as f:
+    f.write("".join("scan%d\n" % (s + 1) for s in range(n_scans)))
+print("generated %d scans x %d views in %.1f s, %.1f MB of JPEG" % (
+    n_scans, n_views, time.time() - t0,
+    sum(os.path.getsize(os.path.join(r, n)) for r, _, fs in os.walk(data) for n in fs) / 1e6), flush=True)
+ckpt = os.path.join(ROOT, "tests", "golden", "params_000007.npz")
+cores = os.cpu_count() or 8
+
+
+def run(tag, extra, scan_list=None):
+    out = os.path.join(base, "out_" + tag)
+    shutil.rmtree(out, ignore_errors=True)
+    argv = ["--input_folder", data, "--output_folder", out, "--checkpoint_path", ckpt, "--scan_list",
+            scan_list or os.path.join(data, "list.txt"), "--num_views", "5", "--output_type", "depth", "--file_format", ".pfm"] + extra
+    t = time.time()
+    pm_eval.main(argv)
+    dt = time.time() - t
+    n = n_scans * n_views if scan_list is None else n_views
+    res = {"config": tag, "samples": n, "seconds": round(dt, 3), "depth_maps_per_s": round(n / dt, 1)}
+    print("RESULT " + json.dumps(res), flush=True)
+    shutil.rmtree(out, ignore_errors=True)
+    return res
+
+
+one = os.path.join(data, "one.txt")
+open(one, "w").write("scan1\n")
+run("warmup", ["--num_workers", "8"], scan_list=one)  # library load, weight packing, graph capture, page cache
+results = []
+for workers in sorted({4, 16, 32, max(cores // 2, 4), max(cores - 2, 4)}):
+    for stream in ("1", "0"):
+        results.append(run("workers%d_stream%s" % (workers, stream), ["--num_workers", str(workers), "--stream_views", stream]))
+results.append(run("default_flags", []))
+results.append(run("workers32_nocache", ["--num_workers", "32", "--feature_cache", "0"]))
+best = max(results, key=lambda r: r["depth_maps_per_s"])
+print("BEST " + json.dumps(best), flush=True)
+shutil.rmtree(base, ignore_errors=True)

@@ -63,6 +63,55 @@ def stage_projections(intr: np.ndarray, extr: np.ndarray, scale: float) -> np.nd
     return proj
 
 
+def arc_cameras(n_views: int, H: int, W: int, step: float = 0.015):
+    """A DTU-like capture: n_views cameras on an arc around the point (0,0,650), ``step`` rad apart about the y axis with a small
+    nod about x, all looking at the surface of ``render_scene`` (neighbouring views overlap almost completely)."""
+    f = 2892.33 * W / 1600.0
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float64)
+    P = np.array([0.0, 0.0, 650.0])
+    extr = []
+    for i in range(n_views):
+        a, b = step * (i - n_views // 2), 0.03 * math.sin(0.7 * i)
+        Ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+        R = Rx @ Ry
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = P - R @ P
+        extr.append(E)
+    return np.stack([K] * n_views).astype(np.float32)[None], np.stack(extr).astype(np.float32)[None]
+
+
+def write_scene_scan(root: str, scan: str, n_views: int, H: int, W: int, n_src: int = 10, seed: int = 0, device="cpu",
+                     quality: int = 95) -> str:
+    """A DTU-layout scan of the photo-consistent scene: ``n_views`` JPEGs rendered from ``arc_cameras``, camera files, and a
+    pair.txt that lists every view's ``n_src`` nearest neighbours on the arc (nearest first, like a DTU pair file)."""
+    import os
+    from PIL import Image
+    d = os.path.join(root, scan)
+    os.makedirs(os.path.join(d, "images"), exist_ok=True)
+    os.makedirs(os.path.join(d, "cams"), exist_ok=True)
+    cams = arc_cameras(n_views, H, W)
+    imgs, intr, extr, _ = render_scene(n_views, H, W, seed=seed, device=device, cameras=cams)
+    for v in range(n_views):
+        arr = (imgs[v][0].permute(1, 2, 0).cpu().numpy() * 255).round().astype(np.uint8)
+        Image.fromarray(arr).save(os.path.join(d, "images", "{:0>8}.jpg".format(v)), quality=quality)
+        with open(os.path.join(d, "cams", "{:0>8}_cam.txt".format(v)), "w") as f:
+            f.write("extrinsic\n")
+            for r in extr[0, v]:
+                f.write(" ".join("%.8f" % x for x in r) + "\n")
+            f.write("\nintrinsic\n")
+            for r in intr[0, v]:
+                f.write(" ".join("%.8f" % x for x in r) + "\n")
+            f.write("\n425.0 935.0\n")
+    with open(os.path.join(d, "pair.txt"), "w") as f:
+        f.write("%d\n" % n_views)
+        for v in range(n_views):
+            others = sorted((u for u in range(n_views) if u != v), key=lambda u: (abs(u - v), u))[:max(n_src, 1)]
+            f.write("%d\n%d " % (v, len(others)) + " ".join("%d %.2f" % (u, 100.0 - abs(u - v)) for u in others) + "\n")
+    return d
+
+
 def write_scan(root: str, scan: str, n_views: int, H: int, W: int, n_src: int = 2) -> str:
     """Writes a DTU-layout scan (images/*.jpg, cams/*_cam.txt, pair.txt) with the synthetic cameras above."""
     import os
@@ -130,13 +179,14 @@ def scene_texture(X, Y, seed: int, n_waves: int = 40):
     return out.clamp_(0.0, 1.0)
 
 
-def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quantise: bool = True, all_depths: bool = False):
+def render_scene(n_views: int, H: int, W: int, seed: int = 0, device="cpu", quantise: bool = True, all_depths: bool = False,
+                 cameras=None):
     """Photo-consistent synthetic sample for ``synthetic_cameras(n_views, H, W)``.
 
     Returns (images: n_views x [1,3,H,W] float32 in {k/255}, intrinsics [1,N,3,3], extrinsics [1,N,4,4],
     depth_gt [H,W] float32 = the surface's depth in the reference view (view 0); with ``all_depths`` a list of the n_views
     ground-truth depth maps, each in its own camera -- a geometrically consistent set of maps for the fusion tests)."""
-    intr, extr = synthetic_cameras(n_views, H, W)
+    intr, extr = synthetic_cameras(n_views, H, W) if cameras is None else cameras  # cameras: ([1,N,3,3], [1,N,4,4]) to override
     dev = torch.device(device)
     v, u = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=dev), torch.arange(W, dtype=torch.float64, device=dev),
                           indexing="ij")
