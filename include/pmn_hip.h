@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 12
+#define PMN_ABI_VERSION 13
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -165,6 +165,17 @@ int pmn_conv3x3_wino(const float *in, const float *weights, const float *shift, 
  * out [N,(H-1)/2+1,(W-1)/2+1,cout].  Supported (cin,cout): (8,16), (16,32), (32,64). */
 int pmn_conv5x5s2_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int cin,
                        int cout, int relu, void *stream);
+
+/* FeatureNet's ConvBnReLU layers conv2..conv10 (reference models/net.py:20-31: 3x3 stride 1 with cin == cout in {16,32,64}; 5x5
+ * stride 2 with (cin,cout) in {(8,16),(16,32),(32,64)}) on the FP16 matrix cores with SPLIT operands: every activation and every
+ * weight is x = hi + lo/2048 (hi = fp16(x), lo = fp16((x-hi)*2048): 22 significant bits), and sum x*w is evaluated as
+ * sum hi*hi + (sum hi*lo + sum lo*hi)/2048 -- three v_mfma_f32_16x16x32_f16 per k-step with fp32 accumulation, 16/3 the rate of
+ * v_mfma_f32_16x16x4_f32, the error of an fp32 direct convolution (2-4e-7 of the output scale; scripts/fp16_split_study.py).
+ * in [N,H,W,cin] channels-last float32; weights DEVICE float16 [cin/CC][k-steps][cout/16][2][64][8] (hi | lo B operands in lane
+ * order, BatchNorm scale folded in float64: patchmatchnet_amd/params.py pack_conv_f16s); shift DEVICE float[cout]; out
+ * [N,(H-1)/stride+1,(W-1)/stride+1,cout] float32 (padding k/2). */
+int pmn_conv2d_f16s(const float *in, const void *weights, const float *shift, float *out, int N, int H, int W, int cin, int cout,
+                    int k, int stride, int relu, void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

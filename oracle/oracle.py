@@ -61,6 +61,10 @@ def lib() -> ctypes.CDLL:
         L.pmo_weighted_neighbor_sum.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, i64, _f32p]
         L.pmo_view_accumulate.argtypes = [_f32p, _f32p, ctypes.c_int, i64, _f32p, _f32p]
         L.pmo_view_normalise.argtypes = [_f32p, _f32p, ctypes.c_int, i64]
+        if "OMP_NUM_THREADS" not in os.environ:
+            # default cap: on a 256-thread host the per-call OpenMP regions are 7x SLOWER with all threads than with 8 (they fight
+            # torch's own pool; bench.py's cpu_baseline: 2.3 s -> 16 s for one cascade); set_num_threads() overrides
+            L.pmo_set_num_threads(min(os.cpu_count() or 1, 32))
         _LIB = L
     return _LIB
 

@@ -1,0 +1,216 @@
+// conv_f16s.hip -- FeatureNet's 16..64-channel ConvBnReLU layers (reference models/net.py:20-31: conv2..conv10, 3x3 stride 1 and
+// 5x5 stride 2) on the FP16 matrix cores with SPLIT operands: fp32-convolution accuracy at a multiple of the fp32 MFMA rate.
+//
+// Why.  gfx950's fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate, 1/16 of v_mfma_f32_16x16x32_f16, and there is
+// no xf32 form.  Every value is split on the fly into two fp16 numbers,
+//       x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)            (22 significant bits; lo stays in fp16's normal range)
+// and the convolution is evaluated as
+//       sum x*w  ~=  sum hi_x*hi_w  +  ( sum hi_x*lo_w + sum lo_x*hi_w ) / 2048        (the lo*lo term, 2^-22, is dropped)
+// Products of two fp16 numbers are exact in fp32 and the MFMA accumulates in fp32, so the result carries 2-4e-7 of the output scale
+// -- what an fp32 direct convolution of the same layer carries (scripts/fp16_split_study.py on the checkpoint's own layers and
+// activations; tests/test_f16s_emulation.py).  Three fp16 MFMAs per k-step instead of one fp32 MFMA over a K 8 times shorter:
+// 16/3 = 5.3x the fp32 matrix rate, which turns these layers from matrix-pipe-bound into HBM-bound.
+//
+// Mapping.  Implicit GEMM, rows = output pixels, columns = output channels, k = (tap, input channel).  Workgroup = 4 waves =
+// a 16 x (4 MT) block of output pixels; wave w owns output rows [w MT, (w+1) MT) -- MT M-tiles of 16 consecutive pixels of one row --
+// and ALL cout/16 N-tiles.  Per chunk of CC input channels the input patch ((4MT-1) S + K rows x (15 S + K) columns) is loaded
+// once (coalesced float4), split, and kept in LDS as two fp16 planes [row][col][CCP] (CCP = CC + padding, chosen so that the
+// ds_read_b128 lane groups {0-3,12-15,20-27}.. touch 16 distinct 16-byte slots; brute-forced per shape).  The k axis of a chunk is
+// cut into blocks of 8 channels, block q = tap * (CC/8) + cb; a k-step = 4 blocks = one v_mfma_f32_16x16x32_f16:
+//   A  lane (i = lane&15, kb = lane>>4): ONE ds_read_b128 = channels [8 cb, +8) of pixel (row + dy, 16-tile column i*S + dx) for
+//      block q = 4 ks + kb -- hi plane and lo plane
+//   B  host-packed to [chunk][k-step][N-tile][hi|lo][64 lanes][8] fp16 (params.pack_conv_f16s): one contiguous 1 KB load per wave,
+//      L2-resident, one k-step ahead in registers
+//   D  lane holds column n = lane&15 (output channel) of rows 4 (lane>>4) + r (pixels of the tile): two accumulators per tile,
+//      main (hi*hi) and low (hi*lo + lo*hi); epilogue: main + low/2048 + shift (folded BatchNorm), ReLU, channels-last store.
+#include "pmn_common.hpp"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct F16sArgs {
+    int N, H, W, Ho, Wo, relu;
+};
+
+#define PMN_F16S_LO_SCALE 2048.0f
+
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __restrict__ in, const f16x8* __restrict__ wB,
+                                                             const float* __restrict__ shift, float* __restrict__ out,
+                                                             const F16sArgs a) {
+    constexpr int NT = COUT / 16, NCB = CC / 8, CHUNKS = CIN / CC, NQ = KS * KS * NCB, KSTEPS = (NQ + 3) / 4;
+    constexpr int TH = 4 * MT, TW = 16, PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PAD = KS / 2;
+    constexpr int PLANE = PH * PW * CCP;  // halves per plane
+    constexpr int NTHR = 256;
+    static_assert(CCP % 8 == 0 && CC % 8 == 0 && CIN % CC == 0, "16-byte aligned channel blocks");
+    extern __shared__ float4 f16s_lds4[];
+    _Float16* Phi = reinterpret_cast<_Float16*>(f16s_lds4);
+    _Float16* Plo = Phi + PLANE;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kb = lane >> 4;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+
+    f32x4_t accM[MT][NT], accL[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            accM[t][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            accL[t][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+
+    const f16x8* bl = wB + lane;  // element (((ch * KSTEPS + ks) * NT + nt) * 2 + split) * 64 + lane
+    f16x8 bq[2][NT][2];           // B operands of two consecutive k-steps (compile-time indexed: the k loop is fully unrolled)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bq[0][nt][0] = bl[(size_t)((0 * NT + nt) * 2 + 0) * 64];
+        bq[0][nt][1] = bl[(size_t)((0 * NT + nt) * 2 + 1) * 64];
+    }
+
+#pragma unroll 1
+    for (int ch = 0; ch < CHUNKS; ++ch) {
+        if (ch) __syncthreads();  // every wave is done with the previous chunk's patch
+        {   // ---- patch: PH x PW pixels x CC/4 channel quads -> split -> two fp16 planes; SB loads of a thread in flight per batch
+            constexpr int QP = CC / 4, TOT = PH * PW * QP, NL = (TOT + NTHR - 1) / NTHR, SB = 6;
+#pragma unroll
+            for (int k0 = 0; k0 < NL; k0 += SB) {
+                float4 v[SB];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int idx = tid + (k0 + k) * NTHR, pix = idx / QP, q4 = idx - pix * QP;
+                    const int py = pix / PW, px = pix - py * PW;
+                    const int gy = iy0 + py, gx = ix0 + px;
+                    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + k < NL && idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                        v[k] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + ch * CC + 4 * q4);
+                }
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int idx = tid + (k0 + k) * NTHR, pix = idx / QP, q4 = idx - pix * QP;
+                    if (k0 + k < NL && idx < TOT) {
+                        const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                        f16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const _Float16 h = (_Float16)x[e];  // round to nearest even
+                            hi[e] = h;
+                            lo[e] = (_Float16)((x[e] - (float)h) * PMN_F16S_LO_SCALE);  // x - hi is exact in fp32
+                        }
+                        *reinterpret_cast<f16x4*>(Phi + pix * CCP + 4 * q4) = hi;
+                        *reinterpret_cast<f16x4*>(Plo + pix * CCP + 4 * q4) = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- k loop of the chunk (fully unrolled; the fences keep hipcc from hoisting every B load to the top) ---------------
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int cur = ks & 1, nxt = cur ^ 1;
+            // next k-step's B operands (runs on into the next chunk; the very last step re-reads itself)
+            {
+                const int step = ch * KSTEPS + ks + 1;
+                const int lim = CHUNKS * KSTEPS - 1;
+                const int sidx = step < lim ? step : lim;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bq[nxt][nt][0] = bl[(size_t)((sidx * NT + nt) * 2 + 0) * 64];
+                    bq[nxt][nt][1] = bl[(size_t)((sidx * NT + nt) * 2 + 1) * 64];
+                }
+            }
+            // this lane's k-block: q = 4 ks + kb -> (tap, channel block); padding blocks (zero weights) read block NQ - 1
+            int q = 4 * ks + kb;
+            if (4 * ks + 3 >= NQ) q = q < NQ - 1 ? q : NQ - 1;
+            const int tap = q / NCB, cb = q - tap * NCB;
+            const int dy = tap / KS, dx = tap - dy * KS;
+            const _Float16* pa = Phi + ((wave * MT * S + dy) * PW + li * S + dx) * CCP + cb * 8;
+            f16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(pa + t * S * PW * CCP);
+                al[t] = *reinterpret_cast<const f16x8*>(pa + t * S * PW * CCP + PLANE);
+            }
+            // three passes, every accumulator once per pass: no back-to-back dependent MFMAs
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accM[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][0], accM[t][nt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accL[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][1], accL[t][nt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accL[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bq[cur][nt][0], accL[t][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (KSTEPS & 1) {  // an odd number of k-steps leaves the prefetched operands in slot 1: the next chunk starts from slot 0
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bq[0][nt][0] = bq[1][nt][0];
+                bq[0][nt][1] = bq[1][nt][1];
+            }
+        }
+    }
+
+    // ---- epilogue: main + low / 2048 + shift (folded BatchNorm), ReLU; lane = output channel 16 nt + li, rows 4 kb + r = pixels
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float sh = shift[nt * 16 + li];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int oy = oy0 + wave * MT + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + 4 * kb + r;
+                float v = accM[t][nt][r] + accL[t][nt][r] * (1.0f / PMN_F16S_LO_SCALE) + sh;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + nt * 16 + li] = v;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS>
+static int launch_f16s(const float* in, const void* w, const float* shift, float* out, F16sArgs a, hipStream_t st) {
+    constexpr int TH = 4 * MT, PH = (TH - 1) * S + KS, PW = 15 * S + KS;
+    const size_t lds = (size_t)2 * PH * PW * CCP * sizeof(_Float16);
+    auto kern = conv_f16s_kernel<CIN, COUT, KS, S, CC, CCP, MT, WPS>;
+    if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
+    const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f16x8*>(w), shift, out, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// in [N,H,W,cin] channels-last float32; weights DEVICE fp16 [cin/CC][k-steps][cout/16][2][64][8] (params.pack_conv_f16s); shift
+// DEVICE float[cout]; out [N,Ho,Wo,cout] float32 with Ho = (H-1)/stride + 1 (padding k/2).  Supported (k, stride, cin, cout):
+// (3,1,16,16), (3,1,32,32), (3,1,64,64), (5,2,8,16), (5,2,16,32), (5,2,32,64) -- FeatureNet's conv2..conv10.
+extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float* shift, float* out, int N, int H, int W, int cin,
+                               int cout, int k, int stride, int relu, void* stream) {
+    if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    F16sArgs a;
+    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.Ho = (H - 1) / (stride > 0 ? stride : 1) + 1;
+    a.Wo = (W - 1) / (stride > 0 ? stride : 1) + 1;
+    hipStream_t st = (hipStream_t)stream;
+    //                                                            CIN COUT KS S  CC CCP MT WPS
+    if (k == 3 && stride == 1 && cin == 16 && cout == 16) return launch_f16s<16, 16, 3, 1, 16, 16, 4, 4>(in, weights, shift, out, a, st);
+    if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 32, 48, 4, 2>(in, weights, shift, out, a, st);
+    if (k == 3 && stride == 1 && cin == 64 && cout == 64) return launch_f16s<64, 64, 3, 1, 32, 48, 4, 2>(in, weights, shift, out, a, st);
+    if (k == 5 && stride == 2 && cin == 8 && cout == 16) return launch_f16s<8, 16, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
+    if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
+    if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
+    return PMN_ERR_SHAPE;
+}

@@ -42,6 +42,9 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
+        # forward_hip: conv2..conv10 on the FP16 matrix cores with split (hi + lo/2048) operands: fp32-convolution accuracy at 16/3
+        # the fp32 MFMA rate (csrc/conv_f16s.hip).  False = rounds 1-2's fp32 Winograd / fp32 MFMA kernels (flags below).
+        self.f16_split = True
         self.winograd5 = True  # forward_hip: conv2, conv5, conv8 (5x5 stride 2) in phase-decomposed Winograd form
         self.winograd = True  # forward_hip: conv3/4, conv6/7, conv9/10 in Winograd F(2x2,3x3) form (False = direct convolutions)
         self.mfma_convs = True  # forward_hip: conv5..conv10 on the fp32 matrix cores (False = VALU kernel for every layer)
@@ -68,6 +71,10 @@ class FeatureNet(nn.Module):
                     w, s = params.pack_conv_mfma(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                if (cv.kernel_size[0], cv.stride[0], cv.in_channels, cv.out_channels) in ops.F16S_SHAPES:
+                    w, s = params.pack_conv_f16s(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
+                                                 eps=m.bn.eps)
+                    pk[f"conv{i}_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
                 if cv.kernel_size[0] == 3 and cv.stride[0] == 1 and cv.in_channels == cv.out_channels and \
                         cv.in_channels in (16, 32, 64):
                     w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
@@ -106,7 +113,9 @@ class FeatureNet(nn.Module):
         for i, (k, s, p) in enumerate(self._SPEC):
             if i < 2:
                 continue
-            if self.winograd and f"conv{i}_wino" in pk:  # 3x3 stride-1 layers: Winograd F(2x2,3x3) on the matrix cores
+            if self.f16_split and f"conv{i}_f16s" in pk:  # fp16 matrix cores, split operands
+                t = ops.conv2d_f16s(t, *pk[f"conv{i}_f16s"], k, s, relu=True)
+            elif self.winograd and f"conv{i}_wino" in pk:  # 3x3 stride-1 layers: Winograd F(2x2,3x3) on the matrix cores
                 t = ops.conv3x3_wino(t, *pk[f"conv{i}_wino"], relu=True)
             elif self.winograd5 and f"conv{i}_wino5" in pk:  # 5x5 stride-2 layers: four parity sub-convolutions in Winograd form
                 t = ops.conv5x5s2_wino(t, *pk[f"conv{i}_wino5"], relu=True)

@@ -443,6 +443,32 @@ def conv5x5s2_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, 
     return out
 
 
+F16S_SHAPES = {(3, 1, 16, 16), (3, 1, 32, 32), (3, 1, 64, 64), (5, 2, 8, 16), (5, 2, 16, 32), (5, 2, 32, 64)}  # (k, stride, cin, cout)
+
+
+def conv2d_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, k: int, stride: int, relu: bool = True) -> torch.Tensor:
+    """pmn_conv2d_f16s: convolution (padding k // 2) + folded-BN shift + ReLU on the FP16 matrix cores with split (hi + lo/2048)
+    operands -- fp32-convolution accuracy; x [N,H,W,cin] channels-last float32, weights float16 from params.pack_conv_f16s ->
+    [N,(H-1)//stride+1,(W-1)//stride+1,cout] float32."""
+    _dev(x, "x")
+    _dev(shift, "shift")
+    if not isinstance(weights, torch.Tensor) or not weights.is_cuda or weights.dtype != torch.float16 or not weights.is_contiguous():
+        raise PmnError("conv2d_f16s: weights must be a contiguous float16 tensor on a ROCm GPU (params.pack_conv_f16s)")
+    N, H, W, cin = x.shape
+    cout = shift.shape[0]
+    if (k, stride, cin, cout) not in F16S_SHAPES:
+        raise PmnError(f"conv2d_f16s: unsupported layer (k={k}, stride={stride}, cin={cin}, cout={cout})")
+    from . import params as _params
+    cc = _params.f16s_chunk(cin, k)
+    if tuple(weights.shape) != (cin // cc, (k * k * (cc // 8) + 3) // 4, cout // 16, 2, 64, 8):
+        raise PmnError("conv2d_f16s: weights are not in pack_conv_f16s layout for this input")
+    out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d_f16s(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out.data_ptr(), N, H, W, cin, cout, k,
+                                         stride, 1 if relu else 0, _stream(x)), "pmn_conv2d_f16s")
+    return out
+
+
 def pointwise_split_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int):
     """pmn_conv2d_mfma, 1x1 form: out = x @ W + shift on the matrix cores with the output channels split between two
     channels-last tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights from

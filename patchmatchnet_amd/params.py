@@ -221,6 +221,62 @@ def pack_conv5x5s2_wino(weight: torch.Tensor, bn=None, bias=None, eps: float = B
     return np.ascontiguousarray(t.astype(np.float32)), np.ascontiguousarray(shift.astype(np.float32))
 
 
+F16S_LO_SCALE = 2048.0  # x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 significant bits, lo in fp16's normal range
+
+
+def f16s_chunk(cin: int, ksize: int) -> int:
+    """Input-channel chunk (channels staged in LDS at a time) of pmn_conv2d_f16s for a layer shape."""
+    if ksize == 3:
+        return 16 if cin == 16 else 32
+    return 8 if cin == 8 else 16
+
+
+def split_f16(x: np.ndarray):
+    """float -> (hi, lo) float16 pair with x ~= hi + lo / F16S_LO_SCALE (relative error 2^-22)."""
+    x32 = np.asarray(x, np.float64).astype(np.float32)
+    hi = x32.astype(np.float16)
+    lo = ((x32 - hi.astype(np.float32)) * np.float32(F16S_LO_SCALE)).astype(np.float16)
+    return hi, lo
+
+
+def pack_conv_f16s(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
+    """Conv2d weight [cout,cin,K,K] (3x3 stride 1 or 5x5 stride 2; cin in {8,16,32,64}, cout in {16,32,64}) (+ BatchNorm2d tensors or
+    a conv bias) -> (float16 [chunks, ksteps, cout/16, 2, 64, 8], float32 [cout]) for pmn_conv2d_f16s: the B operands of
+    v_mfma_f32_16x16x32_f16 in lane order, BatchNorm scale folded in (float64), every weight SPLIT into hi / lo float16 parts
+    (``split_f16``).  The GEMM's k axis of one chunk of CC = f16s_chunk(cin, K) input channels is cut into blocks of 8 channels,
+    block q = tap * (CC / 8) + cb  (tap = dy * K + dx, channels [8 cb, 8 cb + 8) of the chunk); k-step ks holds blocks 4 ks .. 4 ks + 3 and
+    lane l = 16 kb + n of output-channel tile nt reads w[cout = 16 nt + n][chunk * CC + 8 cb + e][dy][dx], e = 0..7, for q = 4 ks + kb
+    (zeros for the padding blocks q >= K * K * CC / 8)."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if (K, cin, cout) not in ((5, 8, 16), (3, 16, 16), (5, 16, 32), (3, 32, 32), (5, 32, 64), (3, 64, 64)):
+        raise ValueError("pack_conv_f16s: unsupported layer shape")
+    if bn is not None:
+        g, b, m, v = (_np64(t) for t in bn)
+        sc = g / np.sqrt(v + eps)
+        w = w * sc[:, None, None, None]
+        shift = b - m * sc
+    elif bias is not None:
+        shift = _np64(bias)
+    else:
+        shift = np.zeros(cout)
+    CC = f16s_chunk(cin, K)
+    ncb, chunks, nt = CC // 8, cin // CC, cout // 16
+    nq = K * K * ncb
+    ksteps = (nq + 3) // 4
+    full = np.zeros((chunks, ksteps * 4, cout, 8), np.float64)  # [chunk][q][cout][e]
+    for ch in range(chunks):
+        for q in range(nq):
+            tap, cb = divmod(q, ncb)
+            dy, dx = divmod(tap, K)
+            full[ch, q] = w[:, ch * CC + 8 * cb:ch * CC + 8 * cb + 8, dy, dx]
+    # [chunk][ks][kb][nt][n][e] -> [chunk][ks][nt][kb][n][e]: lane = 16 kb + n
+    full = full.reshape(chunks, ksteps, 4, nt, 16, 8).transpose(0, 1, 3, 2, 4, 5).reshape(chunks, ksteps, nt, 64, 8)
+    hi, lo = split_f16(full)
+    out = np.stack((hi, lo), axis=3)  # [chunk][ks][nt][split][lane][8]
+    return np.ascontiguousarray(out), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

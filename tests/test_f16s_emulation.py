@@ -1,0 +1,113 @@
+"""CPU emulation of pmn_conv2d_f16s (csrc/conv_f16s.hip): the lane layouts of v_mfma_f32_16x16x32_f16, the k-block / tap / chunk
+indexing, the LDS patch addressing and the host-side weight packing (params.pack_conv_f16s) restated in numpy and checked against
+torch's float64 convolution -- the kernel is written against this emulation (there is no GPU in the authoring container), and the
+GPU parity tests (tests/test_hip_parity.py) then check the real thing.  Also pins the NUMERICS of the split-operand scheme: three
+fp16 products per fp32 product (hi*hi, hi*lo, lo*hi; fp32 accumulation) reproduce an fp32 convolution to ~3e-7 of the output scale
+on FeatureNet's own layers (reference models/net.py:17-37; scripts/fp16_split_study.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from patchmatchnet_amd import params
+
+LAYERS = [(5, 2, 8, 16), (3, 1, 16, 16), (5, 2, 16, 32), (3, 1, 32, 32), (5, 2, 32, 64), (3, 1, 64, 64)]  # (K, stride, cin, cout)
+
+
+def emulate(x_nhwc, wpk, shift, K, S, cin, cout, relu=True):
+    """The kernel, wave by wave: x [N,H,W,cin] float32 -> [N,Ho,Wo,cout] float32."""
+    N, H, W, _ = x_nhwc.shape
+    pad = K // 2
+    Ho, Wo = (H - 1) // S + 1, (W - 1) // S + 1
+    CC = params.f16s_chunk(cin, K)
+    ncb, chunks, NT = CC // 8, cin // CC, cout // 16
+    MT = 4 if S == 1 else 2
+    TH, TW = 4 * MT, 16
+    PH, PW = (TH - 1) * S + K, (TW - 1) * S + K
+    nq = K * K * ncb
+    ksteps = (nq + 3) // 4
+    assert wpk.shape == (chunks, ksteps, NT, 2, 64, 8)
+    out = np.zeros((N, Ho, Wo, cout), np.float32)
+    lane = np.arange(64)
+    li, kb = lane % 16, lane // 16
+    for n in range(N):
+        for oy0 in range(0, Ho, TH):
+            for ox0 in range(0, Wo, TW):
+                iy0, ix0 = oy0 * S - pad, ox0 * S - pad
+                acc_main = np.zeros((4, MT, NT, 16, 16), np.float64)  # [wave][t][nt][row i][col n]
+                acc_low = np.zeros((4, MT, NT, 16, 16), np.float64)
+                for ch in range(chunks):
+                    # patch staging: zero outside the image, split into hi / lo planes [PH][PW][CC]
+                    patch = np.zeros((PH, PW, CC), np.float32)
+                    for py in range(PH):
+                        for px in range(PW):
+                            gy, gx = iy0 + py, ix0 + px
+                            if 0 <= gy < H and 0 <= gx < W:
+                                patch[py, px] = x_nhwc[n, gy, gx, ch * CC:(ch + 1) * CC]
+                    phi, plo = params.split_f16(patch)
+                    for wv in range(4):
+                        for ks in range(ksteps):
+                            q = np.minimum(4 * ks + kb, nq - 1)  # padding blocks read a valid address (their weights are 0)
+                            tap, cb = q // ncb, q % ncb
+                            dy, dx = tap // K, tap % K
+                            for t in range(MT):
+                                row = (wv * MT + t) * S + dy
+                                col = li * S + dx
+                                a_hi = phi[row, col][np.arange(64)[:, None], (cb * 8)[:, None] + np.arange(8)[None]].astype(np.float64)
+                                a_lo = plo[row, col][np.arange(64)[:, None], (cb * 8)[:, None] + np.arange(8)[None]].astype(np.float64)
+                                A_hi = np.zeros((16, 32)); A_lo = np.zeros((16, 32))
+                                for e in range(8):
+                                    A_hi[li, 8 * kb + e] = a_hi[:, e]
+                                    A_lo[li, 8 * kb + e] = a_lo[:, e]
+                                for nt in range(NT):
+                                    b_hi = wpk[ch, ks, nt, 0].astype(np.float64)  # [lane][8]: lane = 16 kb + n
+                                    b_lo = wpk[ch, ks, nt, 1].astype(np.float64)
+                                    B_hi = np.zeros((32, 16)); B_lo = np.zeros((32, 16))
+                                    for e in range(8):
+                                        B_hi[8 * kb + e, li] = b_hi[:, e]
+                                        B_lo[8 * kb + e, li] = b_lo[:, e]
+                                    acc_main[wv, t, nt] += A_hi @ B_hi
+                                    acc_low[wv, t, nt] += A_hi @ B_lo + A_lo @ B_hi
+                # epilogue: lane l holds D[row = 4 kb + r][col = n]: pixel ox0 + row, channel 16 nt + n
+                for wv in range(4):
+                    for t in range(MT):
+                        oy = oy0 + wv * MT + t
+                        if oy >= Ho:
+                            continue
+                        for nt in range(NT):
+                            v = acc_main[wv, t, nt] + acc_low[wv, t, nt] / params.F16S_LO_SCALE + shift[16 * nt:16 * nt + 16][None, :]
+                            if relu:
+                                v = np.maximum(v, 0)
+                            for i in range(16):
+                                if ox0 + i < Wo:
+                                    out[n, oy, ox0 + i, 16 * nt:16 * nt + 16] = v[i]
+    return out
+
+
+@pytest.mark.parametrize("K,S,cin,cout", LAYERS)
+def test_emulated_kernel_matches_float64_convolution(K, S, cin, cout):
+    g = torch.Generator().manual_seed(K * 100 + cin)
+    H, W = (21, 37) if S == 1 else (26, 41)  # ragged tiles in both directions
+    x = torch.randn(1, cin, H, W, generator=g) * (torch.rand(1, cin, 1, 1, generator=g) * 4)
+    x[:, :, 3:5, 7:9] = 1e-5 * torch.randn(1, cin, 2, 2, generator=g)  # tiny values: the lo part must not underflow into nothing
+    w = torch.randn(cout, cin, K, K, generator=g) * 0.2
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1,
+          torch.rand(cout, generator=g) + 0.5)
+    wpk, shift = params.pack_conv_f16s(w, bn=bn)
+    got = emulate(x.permute(0, 2, 3, 1).contiguous().numpy(), wpk, shift, K, S, cin, cout)
+    sc = bn[0].double() / torch.sqrt(bn[3].double() + params.BN_EPS)
+    want = F.conv2d(x.double(), w.double() * sc[:, None, None, None], (bn[1].double() - bn[2].double() * sc), S, K // 2).clamp_min(0)
+    want = want.permute(0, 2, 3, 1).numpy()
+    assert got.shape == want.shape
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < 5e-7, err  # fp32-convolution quality (an fp32 direct convolution of these shapes: 2-4e-7)
+
+
+def test_split_keeps_22_bits():
+    x = np.float32(np.random.default_rng(0).standard_normal(10000) * np.logspace(-4, 3, 10000))
+    hi, lo = params.split_f16(x)
+    rec = hi.astype(np.float64) + lo.astype(np.float64) / params.F16S_LO_SCALE
+    err = np.abs(rec - x)
+    big = np.abs(x) >= 2e-4  # hi is a NORMAL fp16 number down to 6.1e-5: 22 bits from there up (fp16 overflows at 65504)
+    assert (err[big] / np.abs(x[big])).max() < 2.0 ** -21
+    assert err[~big].max() < 1e-10  # below that the absolute error is what matters: 2^-24 (fp16 subnormal step) / 2048

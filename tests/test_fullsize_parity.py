@@ -105,7 +105,7 @@ def test_chained_cascade_from_hip_featurenet(scene, H, W, nsrc):
     fnp = [{st: n(f[st].contiguous()) for st in (1, 2, 3)} for f in feats]
     intr, extr = n(s["intrinsics"]), n(s["extrinsics"])
     dmin, dmax = n(s["depth_min"]), n(s["depth_max"])
-    O.set_num_threads(os.cpu_count() or 1)
+    O.set_num_threads(min(os.cpu_count() or 1, 48))  # 256 OpenMP threads next to torch's own pool: 7x SLOWER than 8 (measured)
     # Two oracle runs per (stage, iteration):
     #  * "forced": the oracle consumes the HIP cascade's own previous depth / view weights, i.e. IDENTICAL inputs at every
     #    Evaluation call of the real cascade -> the north star's <= 1e-3 relative, strictly, on every pixel;
@@ -264,7 +264,7 @@ def test_fullsize_stage_against_oracle_cfg3_cfg5(stage, n_src, H, W):
            depth=torch.empty(0, device=DEV) if depth is None else t(depth),
            view_weights=torch.empty(0, device=DEV) if vw is None else t(vw), noise=noise.to(DEV), debug=dbg)
     torch.cuda.synchronize()
-    O.set_num_threads(os.cpu_count() or 1)
+    O.set_num_threads(min(os.cpu_count() or 1, 48))  # 256 OpenMP threads next to torch's own pool: 7x SLOWER than 8 (measured)
     # every Evaluation call on identical inputs: iteration k > 1 of the oracle starts from the HIP path's iteration k-1 depth
     # (what the stage does internally; see test_cfg2_chained_cascade_from_hip_featurenet for why the free-running chain is not
     # a pass / fail criterion)

@@ -387,6 +387,32 @@ def test_conv5x5s2_winograd_against_torch(cin, cout, H, W):
     assert float((got - direct).abs().max() / ref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("k,stride,cin,cout", [(3, 1, 16, 16), (3, 1, 32, 32), (3, 1, 64, 64), (5, 2, 8, 16), (5, 2, 16, 32), (5, 2, 32, 64)])
+@pytest.mark.parametrize("H,W", [(37, 51), (8, 64), (150, 200)])
+def test_conv_f16_split_against_torch(k, stride, cin, cout, H, W):
+    """pmn_conv2d_f16s (fp16 matrix cores, hi + lo/2048 split operands, three MFMAs per k-step) vs F.conv2d + BatchNorm + ReLU in
+    float64: fp32-convolution accuracy (<= 1e-6 of the output scale; an fp32 direct convolution: 2-4e-7), incl. inputs with a wide
+    dynamic range (tiny values next to large ones) and odd sizes (partial tiles, borders), batch 2.  The numpy emulation of the
+    same kernel is tests/test_f16s_emulation.py."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin + H + k)
+    x = torch.randn(2, cin, H, W, generator=gen) * (4.0 * torch.rand(1, cin, 1, 1, generator=gen))
+    x[:, :, 1:4, 2:6] *= 1e-5
+    wt = 0.2 * torch.randn(cout, cin, k, k, generator=gen)
+    bn = (0.5 + torch.rand(cout, generator=gen), 0.1 * torch.randn(cout, generator=gen), 0.1 * torch.randn(cout, generator=gen),
+          0.5 + torch.rand(cout, generator=gen))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, k // 2)
+    ref = torch.relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                                    False, 0.0, 1e-5))
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w, sh = PP.pack_conv_f16s(wt, bn=bn)
+    got = P.ops.conv2d_f16s(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), k, stride, relu=True)
+    assert tuple(got.shape) == (2, ref.shape[2], ref.shape[3], cout)
+    err = float((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-6, err
+
+
 def test_fpn_level8_matrix_core_form_matches_valu_form():
     """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
     P = _gpu()
