@@ -11,6 +11,7 @@ while read -r line; do
 done <<LIST
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAIT_ANY
+SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_VMEM
 LIST
 python - <<'PY'
 import csv,glob,collections,os
@@ -25,9 +26,10 @@ with open(out+'/summary.txt','w') as fo:
     for key,cs in agg.items():
         g=lambda n: (sum(cs[n])/len(cs[n])) if n in cs else 0.0
         cyc=g('GRBM_GUI_ACTIVE')/8.0
-        line='%-66s cyc %8.0f  valu_busy %4.0f%%  valu/wave %6.0f  lds_busy %4.0f%%  lds_conf %4.0f%%  wait_inst %4.0f%%  smem/wave %5.0f\n'%(
+        line='%-66s cyc %8.0f  valu_busy %4.0f%%  valu/wave %6.0f  lds_busy %4.0f%%  lds_conf %4.0f%%  wait_inst %4.0f%%  wait_lds %4.0f%%  mfma/wave %5.0f  mfma16_util %4.0f%%  mfma_busy_raw %10.0f  waves %7.0f\n'%(
             key, cyc, 100*g('SQ_ACTIVE_INST_VALU')*4/1024/max(cyc,1), g('SQ_INSTS_VALU')/max(g('SQ_WAVES'),1),
             100*g('SQ_LDS_IDX_ACTIVE')/256/max(cyc,1), 100*g('SQ_LDS_BANK_CONFLICT')/max(g('SQ_LDS_IDX_ACTIVE'),1),
-            100*g('SQ_WAIT_INST_ANY')/max(g('SQ_WAVE_CYCLES'),1), g('SQ_INSTS_SMEM')/max(g('SQ_WAVES'),1))
+            100*g('SQ_WAIT_INST_ANY')/max(g('SQ_WAVE_CYCLES'),1), 100*g('SQ_WAIT_INST_LDS')/max(g('SQ_WAVE_CYCLES'),1),
+            g('SQ_INSTS_MFMA')/max(g('SQ_WAVES'),1), 100*g('SQ_INSTS_MFMA')*16/1024/max(cyc,1), g('SQ_VALU_MFMA_BUSY_CYCLES'), g('SQ_WAVES'))
         print(line,end=''); fo.write(line)
 PY
