@@ -220,6 +220,9 @@ def main():
                     help="eager single-stream steps after the timed region that carry the HIP events of the roofline figure")
     ap.add_argument("--scene", choices=("surface", "rolled"), default="surface",
                     help="surface = photo-consistent rendered scene (tests/synth.render_scene); rolled = rounds 1-2's images")
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="untimed replays after the W warm-up steps until the clocks / caches have settled (the timed region is still "
+                         "exactly K steps); 0 = only the W warm-up steps")
     ap.add_argument("--steady-seconds", type=float, default=2.0,
                     help="length of the extra steady-state pass reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
@@ -297,6 +300,19 @@ def main():
         launch_note = None
 
         region = {}  # "run": callable(steps) -> seconds, the timed loop in the mode that produced `value` (re-used by steady_state)
+        extra_warmup = [0]
+
+        def settle(one_step):
+            """Untimed steps on top of the W asked for, until --settle-seconds have passed: the first replays after a capture run
+            at ramping clocks (the 100-step figure came out 5 % under the 2-second one); the timed region stays exactly K steps."""
+            t_end = time.perf_counter() + max(args.settle_seconds, 0.0)
+            i = 0
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    one_step(i)
+                    i += 1
+                torch.cuda.synchronize()
+            extra_warmup[0] = i
 
         def timed_eager():
             def run(steps):
@@ -311,6 +327,7 @@ def main():
 
             for i in range(args.warmup):
                 step(i)
+            settle(step)
             region["run"] = run
             return run(args.steps)
 
@@ -337,6 +354,7 @@ def main():
                 err = str(e).split("\n")[0][:120] or "RuntimeError"
             if reduce_scalar(0.0 if err else 1.0, dist.ReduceOp.MIN) < 1.0:
                 return None, err or "capture failed on another rank"
+            settle(replay)
 
             def run(steps):
                 barrier()
@@ -441,6 +459,7 @@ def main():
                        "scene": "photo-consistent rendered surface (tests/synth.render_scene), one texture seed per sample"
                                 if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
+                       "untimed_steps_before_the_timed_region": max(args.warmup, S if not args.eager else 0) + extra_warmup[0],
                        "in_flight": S, "launch": launch_note or ("python, one stream" if args.eager else
                        f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU")},
             "steady_state": None if steady is None else {

@@ -34,9 +34,6 @@ struct F16sArgs {
 };
 
 #define PMN_F16S_LO_SCALE 2048.0f
-#ifndef PMN_F16S_VARIANT
-#define PMN_F16S_VARIANT 0
-#endif
 
 template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __restrict__ in, const f16x8* __restrict__ wB,
@@ -208,24 +205,14 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     a.Ho = (H - 1) / (stride > 0 ? stride : 1) + 1;
     a.Wo = (W - 1) / (stride > 0 ? stride : 1) + 1;
     hipStream_t st = (hipStream_t)stream;
+    // Tile / chunk shapes from a same-box A/B of three build variants (profiles/r03_f16s_ab.log): small chunks (more workgroups per
+    // CU) win where the layer is latency-bound, M = 32 pixels per wave (MT = 2) where the accumulators cap the occupancy.
     //                                                            CIN COUT KS S  CC CCP MT WPS
     if (k == 3 && stride == 1 && cin == 16 && cout == 16) return launch_f16s<16, 16, 3, 1, 16, 16, 4, 4>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 8 && cout == 16) return launch_f16s<8, 16, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
-#if PMN_F16S_VARIANT == 0
-    if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 32, 48, 4, 2>(in, weights, shift, out, a, st);
-    if (k == 3 && stride == 1 && cin == 64 && cout == 64) return launch_f16s<64, 64, 3, 1, 32, 48, 4, 2>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
-#elif PMN_F16S_VARIANT == 1
-    if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 16, 16, 4, 3>(in, weights, shift, out, a, st);
-    if (k == 3 && stride == 1 && cin == 64 && cout == 64) return launch_f16s<64, 64, 3, 1, 16, 16, 4, 2>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 8, 8, 2, 2>(in, weights, shift, out, a, st);
-#else
     if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 16, 16, 2, 4>(in, weights, shift, out, a, st);
     if (k == 3 && stride == 1 && cin == 64 && cout == 64) return launch_f16s<64, 64, 3, 1, 16, 16, 2, 3>(in, weights, shift, out, a, st);
+    if (k == 5 && stride == 2 && cin == 8 && cout == 16) return launch_f16s<8, 16, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
     if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 8, 8, 2, 3>(in, weights, shift, out, a, st);
-#endif
+    if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
     return PMN_ERR_SHAPE;
 }

@@ -226,12 +226,9 @@ F16S_LO_SCALE = 2048.0  # x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - h
 
 def f16s_chunk(cin: int, ksize: int) -> int:
     """Input-channel chunk (channels staged in LDS at a time) of pmn_conv2d_f16s for a layer shape."""
-    import os
-    if os.environ.get("PMN_F16S_VARIANT", "0") != "0":  # A/B builds of csrc/conv_f16s.hip (scripts/gpu_f16s_ab.sh)
-        return 16 if ksize == 3 else 8
     if ksize == 3:
-        return 16 if cin == 16 else 32
-    return 8 if cin == 8 else 16
+        return 16
+    return 16 if cin == 32 else 8
 
 
 def split_f16(x: np.ndarray):

@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--width", "640", "--height", "480", "--steps", "6", "--warmup", "2", "--samples", "3", "--roofline-steps", "4",
-         "--no-cpu-baseline", "--steady-seconds", "0.2"]
+         "--no-cpu-baseline", "--steady-seconds", "0.2", "--settle-seconds", "0.2"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config", "roofline", "single_stream_eager", "steady_state"}
 
