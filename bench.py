@@ -298,6 +298,29 @@ def main():
     main_stream = torch.cuda.current_stream(device)
     with torch.no_grad():
         launch_note = None
+        # ---- roofline pass: HIP events around the pmn_warp_correlate launches ------------------------------------------------
+        # (Runs FIRST, before the timed region: after seconds of three overlapped forwards the part runs 5-6 % slower clocks -- the same
+        # launches 1.06 ms cold, 1.13 ms behind the steady-state pass -- and the rocprofv3 summary this figure must agree with is taken
+        # from a run without that load.)
+        # Launches inside a replayed graph cannot be bracketed by events, and kernels of two overlapped forwards do not have a
+        # duration of their own; the dominant kernel is therefore timed in R eager single-stream steps of the same process, on
+        # the launch stream, every EV-th step (an event pair costs ~10 us of stream time on ROCm -- a blit per record -- 2.5 % of
+        # a step when every launch is bracketed).  The wall clock of this pass is the single-stream eager rate.
+        EV = 4
+        R = max(args.roofline_steps, EV)
+        sampled = len(range(0, R, EV))
+        for i in range(3):
+            step(i)
+        barrier()
+        ops.enable_kernel_timing()
+        t1 = time.perf_counter()
+        for i in range(R):
+            ops.pause_kernel_timing(i % EV != 0)
+            step(i)
+        torch.cuda.synchronize()
+        eager_elapsed = time.perf_counter() - t1
+        recs = ops.disable_kernel_timing()
+
 
         region = {}  # "run": callable(steps) -> seconds, the timed loop in the mode that produced `value` (re-used by steady_state)
         extra_warmup = [0]
@@ -387,25 +410,6 @@ def main():
             n_steady = int(reduce_scalar(float(n_steady), dist.ReduceOp.MAX))  # every rank runs the same count
             steady = (n_steady, reduce_scalar(region["run"](n_steady), dist.ReduceOp.MAX))
 
-        # ---- roofline pass: HIP events around the pmn_warp_correlate launches ------------------------------------------------
-        # Launches inside a replayed graph cannot be bracketed by events, and kernels of two overlapped forwards do not have a
-        # duration of their own; the dominant kernel is therefore timed in R eager single-stream steps of the same process, on
-        # the launch stream, every EV-th step (an event pair costs ~10 us of stream time on ROCm -- a blit per record -- 2.5 % of
-        # a step when every launch is bracketed).  The wall clock of this pass is the single-stream eager rate.
-        EV = 4
-        R = max(args.roofline_steps, EV)
-        sampled = len(range(0, R, EV))
-        for i in range(3):
-            step(i)
-        barrier()
-        ops.enable_kernel_timing()
-        t1 = time.perf_counter()
-        for i in range(R):
-            ops.pause_kernel_timing(i % EV != 0)
-            step(i)
-        torch.cuda.synchronize()
-        eager_elapsed = time.perf_counter() - t1
-    recs = ops.disable_kernel_timing()
 
     elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
 

@@ -31,7 +31,7 @@ from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
 from patchmatchnet_amd.graph import GraphedForward
 from patchmatchnet_amd.data_io import image_shape, read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
-from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset, MVSViewListDataset
+from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
 
 
 def print_args(args) -> None:
@@ -130,6 +130,96 @@ class MapWriter:
         self.pool.shutdown(wait=True)
 
 
+class ViewDecodeStream:
+    """Every view of the encode-once groups, decoded ONCE by a pool of THREADS, in the order the samples first need them.
+
+    Why threads: Pillow's JPEG decoder and the numpy / torch copies release the GIL, so N threads decode N images at once; worker
+    PROCESSES (torch DataLoader) fork a process that holds a GPU context -- tens of milliseconds each, 18 s for the 254 workers a
+    256-thread host suggests, more than a whole DTU scan takes to compute (profiles/r03_eval_bench_first.log).  A decoded image
+    (uint8 [H,W,3] as the file stores it -- or float32 [H,W,3] when --image_max_dim down-scales) lands in a pinned buffer from a
+    small pool (back-pressure), goes to the device on a side stream, and becomes the [1,3,H,W] float32 image of
+    datasets/data_io.py:34-47 there (uint8 -> float32 / 255 with a DEVICE divisor: numpy's own float32 division, see
+    DevicePrefetcher).  ``take(n)`` returns up to n consecutive views of one group that are ready (blocks for the first)."""
+
+    def __init__(self, dataset, items, device, threads: int) -> None:
+        import collections
+        self.dataset, self.items, self.device = dataset, list(items), device
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(threads, 1), thread_name_prefix="pmn-decode")
+        self.window = 2 * max(threads, 1) + 4          # decodes in flight / done but not consumed
+        self.pending = collections.deque()             # futures in item order
+        self.submitted = 0
+        self.copy_stream = torch.cuda.Stream(device)
+        self.scale = torch.tensor(255.0, device=device)
+        self.free = {}                                 # (shape, dtype) -> list of free pinned buffers
+        self.busy = []                                 # (event, buffer): pinned buffers whose upload may still be running
+        self.lock = __import__("threading").Lock()
+
+    def _buffer(self, shape, dtype):
+        with self.lock:
+            pool = self.free.setdefault((tuple(shape), dtype), [])
+            if pool:
+                return pool.pop()
+        return torch.empty(tuple(shape), dtype=dtype).pin_memory()
+
+    def _decode(self, item):  # worker thread
+        from patchmatchnet_amd.data_io import read_image, read_image_u8
+        _, scan, light, vid = item
+        path = self.dataset.image_path(scan, light, vid)
+        arr = read_image_u8(path, self.dataset.max_dim)
+        if arr is None:
+            arr, _, _ = read_image(path, self.dataset.max_dim)
+            arr = np.ascontiguousarray(arr, np.float32)
+        buf = self._buffer(arr.shape, torch.uint8 if arr.dtype == np.uint8 else torch.float32)
+        np.copyto(buf.numpy(), arr)
+        return buf
+
+    def _fill(self) -> None:
+        while self.submitted < len(self.items) and len(self.pending) < self.window:
+            self.pending.append((self.items[self.submitted], self.pool.submit(self._decode, self.items[self.submitted])))
+            self.submitted += 1
+
+    def _recycle(self) -> None:
+        still = []
+        for ev, buf in self.busy:
+            if ev.query():
+                with self.lock:
+                    self.free.setdefault((tuple(buf.shape), buf.dtype), []).append(buf)
+            else:
+                still.append((ev, buf))
+        self.busy = still
+
+    def take(self, max_n: int = 4):
+        """[(group, view id, image [1,3,H,W] float32 on the device)], 1..max_n consecutive views of ONE group; the current stream is
+        ordered after their uploads."""
+        self._fill()
+        self._recycle()
+        if not self.pending:
+            raise StopIteration
+        out, group = [], self.pending[0][0][0]
+        while self.pending and len(out) < max_n and self.pending[0][0][0] == group and (not out or self.pending[0][1].done()):
+            item, fut = self.pending.popleft()
+            buf = fut.result()  # re-raises a decode error
+            with torch.cuda.stream(self.copy_stream):
+                raw = buf.to(self.device, non_blocking=True)                       # [H,W,3]
+                img = torch.empty((1, 3, raw.shape[0], raw.shape[1]), dtype=torch.float32, device=self.device)
+                img[0].copy_(raw.permute(2, 0, 1))                                # uint8 -> float32 + HWC -> CHW in one pass
+                if raw.dtype == torch.uint8:
+                    img.div_(self.scale)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.busy.append((ev, buf))
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            img.record_stream(torch.cuda.current_stream(self.device))
+            out.append((item[0], item[3], img))
+            self._fill()
+        return out
+
+    def close(self) -> None:
+        for _, fut in self.pending:
+            fut.cancel()
+        self.pool.shutdown(wait=True)
+
+
 class DevicePrefetcher:
     """Iterates a DataLoader one sample ahead: the next sample's tensors are copied host -> device on a side stream (from the
     loader's pinned memory) while the current one computes; the consumer's stream waits on the copy's event only."""
@@ -215,7 +305,9 @@ def save_depth(args, rank, world, device, on_scan_done=None):
     the samples first need them -- the decode workers live across scans, a sample runs as soon as ITS views are encoded (decode
     overlaps the forwards), and a pyramid is dropped after its last use; --stream_views 0: round 2's two passes per group (decode
     + encode everything, then the samples).  Same maps, bit for bit, as the plain path (tests/test_eval_gpu.py)."""
+    t_stage = time.time()
     model = load_model(args, device)
+    t_loaded = time.time()
     # --hip_graph: one HIP-graph replay per sample instead of ~55 Python-issued launches -- the launch thread is what the
     # uploads and the writer threads compete with; --in_flight S: S samples in flight, each on its own HIP stream with its own
     # replay slot, so that the gathers of one sample (vector-memory pipe) share the CUs with the convolutions of the other
@@ -274,12 +366,7 @@ def save_depth(args, rank, world, device, on_scan_done=None):
                     if v not in seen:
                         seen.add(v)
                         view_items.append((gi, scan, light, v))
-    view_stream = None
-    if view_items:
-        vds = MVSViewListDataset(dataset, view_items)
-        kw = dict(prefetch_factor=2, persistent_workers=True) if args.num_workers > 0 else {}
-        vloader_all = DataLoader(vds, batch_sampler=vds.batches(4), num_workers=args.num_workers, pin_memory=True, **kw)
-        view_stream = iter(DevicePrefetcher(vloader_all, device, keys=("image",)))
+    view_stream = ViewDecodeStream(dataset, view_items, device, args.decode_threads) if view_items else None
 
     def run_group_streaming(gi, scan, light, indices):
         """Samples of one group from cameras only; views are pulled from the shared decode stream as the samples need them."""
@@ -297,15 +384,14 @@ def save_depth(args, rank, world, device, on_scan_done=None):
         for k, sample in enumerate(loader):
             start = time.time()
             ids = [int(v) for v in sample["view_ids"][0]]
-            while any(v not in pyramids for v in ids):  # decode stream order = first-use order: the next batches hold them
-                batch = next(view_stream)
-                assert int(batch["group"][0]) == gi, "view stream out of step with the sample order"
-                imgs = batch["image"]
-                f = model.feature.forward_hip(imgs)
-                for j, v in enumerate(batch["view"].tolist()):
+            while any(v not in pyramids for v in ids):  # decode stream order = first-use order: the next views are these
+                batch = view_stream.take(4)
+                assert batch[0][0] == gi, "view stream out of step with the sample order"
+                f = model.feature.forward_hip([img for _, _, img in batch])  # 1..4 views in one FeatureNet pass
+                for j, (_, v, img) in enumerate(batch):
                     pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
                     if v in refs:
-                        images[v] = imgs[j:j + 1]  # Refinement reads the reference image
+                        images[v] = img  # Refinement reads the reference image
                     n_enc += 1
             ref_img = images[ids[0]]
             _seed_sample(args, dataset, sample)
@@ -390,7 +476,14 @@ def save_depth(args, rank, world, device, on_scan_done=None):
             scan_finished(scan)
     for st in streams:
         main_stream.wait_stream(st)
+    if view_stream is not None:
+        view_stream.close()
     writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
+    torch.cuda.synchronize(device)
+    t_end = time.time()
+    print("depth stage: {} samples in {:.3f} s after a {:.3f} s model load -> {:.1f} depth-maps/s on this rank (decode, upload, "
+          "forward, download and map files included)".format(total, t_end - t_loaded, t_loaded - t_stage,
+                                                             total / max(t_end - t_loaded, 1e-9)))
     return produced
 
 
@@ -514,7 +607,11 @@ def build_parser():
     p.add_argument("--photo_thres", type=float, default=0.5, help="threshold for photometric consistency filtering")
     # additions
     p.add_argument("--num_workers", type=int, default=-1,
-                   help="DataLoader (JPEG decode) worker processes per rank; -1 = the host's hardware threads / ranks, minus two")
+                   help="DataLoader worker processes per rank (the path without the feature cache); -1 = min(8, this rank's share of "
+                        "the host's hardware threads)")
+    p.add_argument("--decode_threads", type=int, default=-1,
+                   help="JPEG decode threads per rank of the encode-once path (--feature_cache > 0, --stream_views 1); -1 = min(24, "
+                        "this rank's share of the host's hardware threads)")
     p.add_argument("--sample_seed", type=int, default=-1,
                    help=">= 0: re-seed the device RNG per sample from (this value, scan, reference view) so the stage-3 random "
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
@@ -548,8 +645,11 @@ def main(argv=None):
         raise P.PmnError("eval.py needs a ROCm GPU: the learned-PatchMatch path has no CPU fallback")
     rank, world, device = pdist.init_from_env("cuda")
 
-    if args.num_workers < 0:  # decode workers: the host's cores shared between the ranks of the node
-        args.num_workers = max((os.cpu_count() or 4) // max(world, 1) - 2, 2)
+    share = max((os.cpu_count() or 4) // max(world, 1), 1)  # this rank's share of the host's hardware threads
+    if args.num_workers < 0:  # DataLoader worker PROCESSES (plain path): each forks a process with a GPU context -- keep them few
+        args.num_workers = max(min(share - 2, 8), 2)
+    if args.decode_threads < 0:  # decode THREADS of the encode-once path
+        args.decode_threads = max(min(share - 2, 24), 2)
     if args.output_type == "depth":
         save_depth(args, rank, world, device)
     elif args.output_type == "both":

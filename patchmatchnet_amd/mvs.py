@@ -131,34 +131,3 @@ class MVSViewDataset(Dataset):
         if img is None:
             img, _, _ = read_image(path, self.parent.max_dim)
         return {"image": np.ascontiguousarray(img.transpose(2, 0, 1)), "view": vid}
-
-
-class MVSViewListDataset(Dataset):
-    """An ordered list of (group index, scan, light, view id) images, each decoded ONCE -- eval.py's streaming encode-once path
-    feeds ALL its groups through one DataLoader over this list (views in the order the samples first need them), so the decode
-    workers stay alive across scans and decoding runs ahead of, and overlaps with, the forwards."""
-
-    def __init__(self, parent: MVSDataset, items: List[Tuple[int, str, str, int]]) -> None:
-        super().__init__()
-        self.parent, self.items = parent, list(items)
-
-    def __len__(self) -> int:
-        return len(self.items)
-
-    def __getitem__(self, idx: int) -> Dict:
-        group, scan, light, vid = self.items[idx]
-        path = self.parent.image_path(scan, light, vid)
-        img = read_image_u8(path, self.parent.max_dim) if self.parent.uint8_images else None
-        if img is None:
-            img, _, _ = read_image(path, self.parent.max_dim)
-        return {"image": np.ascontiguousarray(img.transpose(2, 0, 1)), "view": vid, "group": group}
-
-    def batches(self, max_batch: int = 4) -> List[List[int]]:
-        """Index batches for DataLoader(batch_sampler=...): consecutive items of the SAME group (one image size), <= max_batch."""
-        out: List[List[int]] = []
-        for i, it in enumerate(self.items):
-            if out and len(out[-1]) < max_batch and self.items[out[-1][-1]][0] == it[0]:
-                out[-1].append(i)
-            else:
-                out.append([i])
-        return out

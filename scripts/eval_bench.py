@@ -2,8 +2,9 @@
 """eval.py END TO END with the JPEG decode in: a generated DTU-layout scan of the photo-consistent
 scene (tests/synth.write_scene_scan: 49 views, 1600x1200, JPEG quality 95, on tmpfs), eval.py --num_views 5 --output_type depth
 (decode -> upload -> FeatureNet once per view -> cascade -> refinement -> download -> PFM files), feature cache on, swept over the
-number of decode workers and the two encode-once schedules (--stream_views 1: one persistent decode stream overlapped with the
-forwards; 0: round 2's two passes per scan).  Prints depth-maps/s per configuration = samples / wall time of eval.main()
+number of decode THREADS of the streaming encode-once schedule (--stream_views 1: views decoded once, in first-use order, by a
+thread pool, overlapped with the forwards), against round 2's two passes per scan over DataLoader worker processes and against the
+reference's schedule (no cache: every sample decodes and encodes its six images).  Prints depth-maps/s per configuration = samples / wall time of eval.main()
 (model load and graph capture included in the first, excluded by a warm-up run before the sweep).
 
     python scripts/eval_bench.py [n_scans=2] [n_views=49]
@@ -20,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth  # noqa: E402
 import eval as pm_eval  # noqa: E402
 
-n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 n_views = int(sys.argv[2]) if len(sys.argv) > 2 else 49
 base = "/dev/shm/pmn_eval_bench" if os.path.isdir("/dev/shm") else "/tmp/pmn_eval_bench"
 shutil.rmtree(base, ignore_errors=True)
@@ -54,13 +55,13 @@ def run(tag, extra, scan_list=None):
 
 one = os.path.join(data, "one.txt")
 open(one, "w").write("scan1\n")
-run("warmup", ["--num_workers", "8"], scan_list=one)  # library load, weight packing, graph capture, page cache
+run("warmup", ["--decode_threads", "8"], scan_list=one)  # library load, weight packing, graph capture, page cache
 results = []
-for workers in sorted({4, 16, 32, max(cores // 2, 4), max(cores - 2, 4)}):
-    for stream in ("1", "0"):
-        results.append(run("workers%d_stream%s" % (workers, stream), ["--num_workers", str(workers), "--stream_views", stream]))
+for threads in (4, 8, 16, 32, 64):
+    results.append(run("decode_threads%d" % threads, ["--decode_threads", str(threads)]))
 results.append(run("default_flags", []))
-results.append(run("workers32_nocache", ["--num_workers", "32", "--feature_cache", "0"]))
+results.append(run("two_pass_workers8", ["--num_workers", "8", "--stream_views", "0"]))       # round 2's schedule (DataLoader processes)
+results.append(run("nocache_workers8", ["--num_workers", "8", "--feature_cache", "0"], scan_list=one))  # the reference's schedule: 6 decodes + encodes per sample
 best = max(results, key=lambda r: r["depth_maps_per_s"])
 print("BEST " + json.dumps(best), flush=True)
 shutil.rmtree(base, ignore_errors=True)
