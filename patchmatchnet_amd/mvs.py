@@ -25,6 +25,11 @@ class MVSDataset(Dataset):
         self.cam_folder, self.image_folder, self.image_extension = cam_folder, image_folder, image_extension
         self.load_images = True  # False: samples carry cameras and image SHAPES only (eval.py's encode-once path)
         self.uint8_images = False  # True: images that need no down-scaling come as uint8 [3,H,W]; the consumer divides by 255
+        # camera files and image headers are read once per (scan, view), not once per sample the view appears in (a view is the
+        # source of ~num_views other samples; with images served from the feature cache the 12 small file reads of a sample were
+        # the largest item of eval.py's per-sample host time)
+        self._cam_cache: Dict[str, Tuple[np.ndarray, np.ndarray, np.ndarray]] = {}
+        self._shape_cache: Dict[str, Tuple[int, int, int, int]] = {}
         if os.path.isfile(scan_list):
             with open(scan_list) as f:
                 scans = [ln.rstrip() for ln in f.readlines()]
@@ -97,10 +102,14 @@ class MVSDataset(Dataset):
                 images.append(np.ascontiguousarray(img.transpose(2, 0, 1)))
                 hi, wi = img.shape[0], img.shape[1]
             else:
-                hi, wi, h0, w0 = image_shape(path, self.max_dim)
+                if path not in self._shape_cache:
+                    self._shape_cache[path] = image_shape(path, self.max_dim)
+                hi, wi, h0, w0 = self._shape_cache[path]
                 images.append(np.asarray([hi, wi], np.int64))
-            K, E, depth_params = read_cam_file(os.path.join(self.data_path, scan, self.cam_folder,
-                                                            "{:0>8}_cam.txt".format(vid)))
+            cam_path = os.path.join(self.data_path, scan, self.cam_folder, "{:0>8}_cam.txt".format(vid))
+            if cam_path not in self._cam_cache:
+                self._cam_cache[cam_path] = read_cam_file(cam_path)
+            K, E, depth_params = (a.copy() for a in self._cam_cache[cam_path])  # K is rescaled in place below
             K[0] *= wi / w0
             K[1] *= hi / h0
             intrinsics.append(K)

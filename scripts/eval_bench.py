@@ -21,8 +21,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth  # noqa: E402
 import eval as pm_eval  # noqa: E402
 
-n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-n_views = int(sys.argv[2]) if len(sys.argv) > 2 else 49
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_scans = int(pos[0]) if len(pos) > 0 else 6
+n_views = int(pos[1]) if len(pos) > 1 else 49
 base = "/dev/shm/pmn_eval_bench" if os.path.isdir("/dev/shm") else "/tmp/pmn_eval_bench"
 shutil.rmtree(base, ignore_errors=True)
 data = os.path.join(base, "data")
@@ -57,11 +58,21 @@ one = os.path.join(data, "one.txt")
 open(one, "w").write("scan1\n")
 run("warmup", ["--decode_threads", "8"], scan_list=one)  # library load, weight packing, graph capture, page cache
 results = []
-for threads in (4, 8, 16, 32, 64):
+for threads in (4, 8, 16):
     results.append(run("decode_threads%d" % threads, ["--decode_threads", str(threads)]))
 results.append(run("default_flags", []))
-results.append(run("two_pass_workers8", ["--num_workers", "8", "--stream_views", "0"]))       # round 2's schedule (DataLoader processes)
-results.append(run("nocache_workers8", ["--num_workers", "8", "--feature_cache", "0"], scan_list=one))  # the reference's schedule: 6 decodes + encodes per sample
+if "--all" in sys.argv:
+    results.append(run("two_pass_workers8", ["--num_workers", "8", "--stream_views", "0"]))       # round 2's schedule (DataLoader processes)
+    results.append(run("nocache_workers8", ["--num_workers", "8", "--feature_cache", "0"], scan_list=one))  # the reference's schedule
+# where the launch thread's time goes (cProfile of one more default run)
+import cProfile, pstats, io
+pr = cProfile.Profile()
+pr.enable()
+run("default_flags_profiled", [])
+pr.disable()
+buf = io.StringIO()
+pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(28)
+print(buf.getvalue(), flush=True)
 best = max(results, key=lambda r: r["depth_maps_per_s"])
 print("BEST " + json.dumps(best), flush=True)
 shutil.rmtree(base, ignore_errors=True)
