@@ -283,12 +283,15 @@ class PatchmatchNet(nn.Module):
 
     def forward(self, images: List[torch.Tensor], intrinsics: torch.Tensor, extrinsics: torch.Tensor,
                 depth_min: torch.Tensor, depth_max: torch.Tensor, noise: Optional[torch.Tensor] = None,
-                features: Optional[List[Dict[int, torch.Tensor]]] = None, debug: Optional[dict] = None
+                features: Optional[List[Dict[int, torch.Tensor]]] = None, debug: Optional[dict] = None,
+                features_nhwc: Optional[Dict[int, torch.Tensor]] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Dict[int, List[torch.Tensor]]]:
         """Reference arguments (images: N x [B,3,H,W]; intrinsics [B,N,3,3]; extrinsics [B,N,4,4]; depth_min/max [B]).
 
         Optional extras (default = reference behaviour): ``noise`` [B,48,H/8,W/8] pins the stage-3 random draw,
-        ``features`` injects pre-computed FeatureNet outputs, ``debug`` (dict) collects per-stage intermediates.
+        ``features`` injects pre-computed FeatureNet outputs (``features_nhwc``: {stage: [(N+1)*B,h,w,C]} = the SAME maps, view-major
+        in one channels-last buffer per stage -- what ``features[v][stage]`` are views of -- so that the kernels read them in place
+        instead of stacking the source views into a buffer of their own), ``debug`` (dict) collects per-stage intermediates.
         Returns (depth [B,1,H,W], photometric confidence [B,H,W] (empty in training mode), {stage: [depths]})."""
         assert len(images) == intrinsics.size()[1], "Different number of images and intrinsic matrices"
         assert len(images) == extrinsics.size()[1], "Different number of images and extrinsic matrices"
@@ -302,6 +305,8 @@ class PatchmatchNet(nn.Module):
         stacked: Dict[int, torch.Tensor] = {}
         if features is None:
             features = self.extract_features(images, stacked)
+        elif features_nhwc is not None:
+            stacked.update({("nhwc", st): t for st, t in features_nhwc.items()})
         ref_feature, src_features = features[0], features[1:]
         batch = ref_image.shape[0]
 
