@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 13
+#define PMN_ABI_VERSION 14
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -218,6 +218,12 @@ int pmn_stage_projections(const float *intrinsics, const float *extrinsics, int 
  * -> out [N,H,W,8] channels-last. */
 int pmn_stem(const float *img, const float *w0, const float *s0, const float *w1, const float *s1, float *out, int N, int H,
              int W, void *stream);
+
+/* The same stem with conv1 (72 % of its multiplies) on the FP16 matrix cores with split operands (see pmn_conv2d_f16s): conv0 on the
+ * fp32 VALU into LDS, split into hi / lo fp16 planes there, conv1 as three v_mfma_f32_16x16x32_f16 per k-step with the output channels
+ * as MFMA rows.  w1a DEVICE float16 [3][2][64][8] (patchmatchnet_amd/params.py pack_stem_conv1_f16s); everything else as pmn_stem. */
+int pmn_stem_f16s(const float *img, const float *w0, const float *s0, const void *w1a, const float *s1, float *out, int N, int H,
+                  int W, void *stream);
 
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */

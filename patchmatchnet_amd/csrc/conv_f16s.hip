@@ -216,3 +216,150 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
     return PMN_ERR_SHAPE;
 }
+
+
+// =================================================================================================================================
+// Fused stem on the fp16 matrix cores: conv0 (3 -> 8, fp32 VALU, as pmn_stem) feeds conv1 (8 -> 8: 72 % of the stem's multiplies)
+// as split-operand MFMAs.  reference models/net.py:17-19, 51.
+//
+// Workgroup = 16 x 16 output pixels.  (1) planar 20 x 20 x 3 input patch -> LDS; (2) every thread evaluates conv0 + BatchNorm + ReLU
+// for its pixels of the 18 x 18 halo patch (zero outside the image: conv1 pads conv0's OUTPUT map), splits the 8 channels into hi / lo
+// fp16 and writes two planes [18][18][8 halves] (16 B per pixel: a ds_read_b128 lane group {pixels i} x {tap q, tap q + 1} touches 16
+// distinct slots or the same address -- brute-forced); (3) conv1 with the ROLES SWAPPED: the MFMA's A operand (rows) = the 8 output
+// channels (rows 8..15 zero), the B operand (columns) = 16 consecutive pixels of one output row, k = (tap, channel): 9 blocks of 8
+// channels = 3 k-steps (3 padding blocks).  D then holds, in lane (pixel i, kb), output channels 4 kb .. 4 kb + 3 of pixel i for kb = 0, 1:
+// one float4 store per lane, 512 contiguous bytes per 16-pixel row of the channels-last output.  Wave w owns output rows 4 w .. 4 w + 3.
+// =================================================================================================================================
+__global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
+                                                          const float* __restrict__ s0, const f16x8* __restrict__ w1A,
+                                                          const float* __restrict__ s1, float* __restrict__ out, const int N,
+                                                          const int H, const int W) {
+    constexpr int TW = 16, TH = 16, IW = 20, IWP = 21, MW = 18, NTHR = 256;
+    __shared__ float xin[3 * IW * IWP];
+    __shared__ float4 mid4[2 * MW * MW];  // two planes of MW*MW pixels x 8 halves (16 B)
+    _Float16* midh = reinterpret_cast<_Float16*>(mid4);
+    _Float16* midl = midh + MW * MW * 8;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
+    const cfloat* cs0 = (const cfloat*)s0;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kb = lane >> 4;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+
+    // conv1's weights (A operands of the three k-steps, hi | lo): six 1 KB loads per wave, in flight across the staging below
+    f16x8 wa[3][2];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        wa[ks][0] = w1A[(ks * 2 + 0) * 64 + lane];
+        wa[ks][1] = w1A[(ks * 2 + 1) * 64 + lane];
+    }
+    {   // (1) input patch, every load of the thread in flight before the first LDS write
+        constexpr int NL = (3 * IW * IW + NTHR - 1) / NTHR;
+        float v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + u * NTHR;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            const int gy = oy0 - 2 + r, gx = ox0 - 2 + q;
+            v[u] = 0.0f;
+            if (idx < 3 * IW * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v[u] = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + u * NTHR;
+            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
+            if (idx < 3 * IW * IW) xin[(c * IW + r) * IWP + q] = v[u];
+        }
+    }
+    __syncthreads();
+    // (2) conv0 + BN + ReLU on the halo patch (fp32, same order of operations as stem_kernel) -> hi / lo planes
+    for (int m = tid; m < MW * MW; m += NTHR) {
+        const int r = m / MW, q = m - r * MW;
+        const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const cfloat* wq = cw0 + __builtin_amdgcn_readfirstlane(ky * 72);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = xin[(ci * IW + r + ky) * IWP + q + kx];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wq[(kx * 3 + ci) * 8 + c], acc[c]);
+                }
+        }
+        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float x = inside ? fmaxf(acc[c] + cs0[c], 0.0f) : 0.0f;
+            const _Float16 h = (_Float16)x;
+            hi[c] = h;
+            lo[c] = (_Float16)((x - (float)h) * PMN_F16S_LO_SCALE);
+        }
+        *reinterpret_cast<f16x8*>(midh + m * 8) = hi;
+        *reinterpret_cast<f16x8*>(midl + m * 8) = lo;
+    }
+    __syncthreads();
+    // (3) conv1: D[cout][pixel] += W[cout][k] * mid[k][pixel]
+    f32x4_t accM[4], accL[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        accM[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        accL[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        int q = 4 * ks + kb;
+        q = q < 8 ? q : 8;  // padding blocks 9..11 (zero weights) read tap 8
+        const int dy = q / 3, dx = q - dy * 3;
+        const _Float16* pb = midh + ((wave * 4 + dy) * MW + li + dx) * 8;
+        f16x8 bh[4], blo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bh[t] = *reinterpret_cast<const f16x8*>(pb + t * MW * 8);
+            blo[t] = *reinterpret_cast<const f16x8*>(pb + t * MW * 8 + MW * MW * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][0], bh[t], accM[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][0], blo[t], accL[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][1], bh[t], accL[t], 0, 0, 0);
+    }
+    // D rows 4 kb + r = output channels: lanes with kb < 2 hold channels [4 kb, 4 kb + 4) of pixel (ox0 + li, oy0 + 4 wave + t)
+    if (kb < 2) {
+        const float4 sh = *reinterpret_cast<const float4*>(s1 + 4 * kb);
+        const int ox = ox0 + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oy = oy0 + wave * 4 + t;
+            if (oy < H && ox < W) {
+                float4 v;
+                v.x = fmaxf(accM[t][0] + accL[t][0] * (1.0f / PMN_F16S_LO_SCALE) + sh.x, 0.0f);
+                v.y = fmaxf(accM[t][1] + accL[t][1] * (1.0f / PMN_F16S_LO_SCALE) + sh.y, 0.0f);
+                v.z = fmaxf(accM[t][2] + accL[t][2] * (1.0f / PMN_F16S_LO_SCALE) + sh.z, 0.0f);
+                v.w = fmaxf(accM[t][3] + accL[t][3] * (1.0f / PMN_F16S_LO_SCALE) + sh.w, 0.0f);
+                *reinterpret_cast<float4*>(out + (((size_t)n * H + oy) * W + ox) * 8 + 4 * kb) = v;
+            }
+        }
+    }
+}
+
+// img [N,3,H,W] planar; w0 [3][3][3][8] / s0 [8] (pack_conv layout, fp32); w1a DEVICE fp16 [3][2][64][8] (params.pack_stem_conv1_f16s:
+// conv1's weights as MFMA A operands, hi | lo, BatchNorm scale folded in float64); s1 [8] -> out [N,H,W,8] channels-last float32.
+extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0, const void* w1a, const float* s1, float* out,
+                             int N, int H, int W, void* stream) {
+    if (!img || !w0 || !s0 || !w1a || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
+    hipLaunchKernelGGL(stem_f16s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+                       reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

@@ -85,6 +85,10 @@ class FeatureNet(nn.Module):
                     w, s = params.pack_conv5x5s2_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean,
                                                                      m.bn.running_var), eps=m.bn.eps)
                     pk[f"conv{i}_wino5"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            m1 = self.conv1
+            w, s = params.pack_stem_conv1_f16s(m1.conv.weight, bn=(m1.bn.weight, m1.bn.bias, m1.bn.running_mean, m1.bn.running_var),
+                                              eps=m1.bn.eps)
+            pk["conv1_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             for name in ("output1", "inner1", "inner2", "output2", "output3"):
                 m = getattr(self, name)
                 w, s = params.pack_conv(m.weight, bias=m.bias)
@@ -107,8 +111,11 @@ class FeatureNet(nn.Module):
         imgs = list(x) if isinstance(x, (list, tuple)) else [x]
         B, _, H, W = imgs[0].shape
         t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
-        for i, im in enumerate(imgs):  # conv0 + conv1 fused (pmn_stem)
-            ops.stem(im.contiguous(), *pk["conv0"], *pk["conv1"], out=t[i * B:(i + 1) * B])
+        for i, im in enumerate(imgs):  # conv0 + conv1 fused (pmn_stem_f16s: conv1 on the fp16 matrix cores; pmn_stem: all fp32 VALU)
+            if self.f16_split:
+                ops.stem_f16s(im.contiguous(), *pk["conv0"], *pk["conv1_f16s"], out=t[i * B:(i + 1) * B])
+            else:
+                ops.stem(im.contiguous(), *pk["conv0"], *pk["conv1"], out=t[i * B:(i + 1) * B])
         feats = {}
         for i, (k, s, p) in enumerate(self._SPEC):
             if i < 2:

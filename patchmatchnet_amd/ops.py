@@ -597,6 +597,30 @@ def stem(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1: torch.Tensor
     return out
 
 
+def stem_f16s(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1a: torch.Tensor, s1: torch.Tensor,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pmn_stem_f16s: FeatureNet conv0 (fp32 VALU) + conv1 (fp16 matrix cores, split operands) fused; img [N,3,H,W] -> [N,H,W,8]
+    (optionally into ``out``); w1a = params.pack_stem_conv1_f16s (float16 [3,2,64,8])."""
+    for n_, t_ in (("img", img), ("w0", w0), ("s0", s0), ("s1", s1)):
+        _dev(t_, n_)
+    if not isinstance(w1a, torch.Tensor) or not w1a.is_cuda or w1a.dtype != torch.float16 or tuple(w1a.shape) != (3, 2, 64, 8) \
+            or not w1a.is_contiguous():
+        raise PmnError("stem_f16s: w1a must be the float16 [3,2,64,8] tensor of params.pack_stem_conv1_f16s on a ROCm GPU")
+    N, c, H, W = img.shape
+    if c != 3 or tuple(w0.shape) != (3, 3, 3, 8):
+        raise PmnError("stem_f16s: expects a 3-channel image and 3->8 conv0 weights")
+    if out is None:
+        out = torch.empty((N, H, W, 8), dtype=torch.float32, device=img.device)
+    else:
+        _dev(out, "out")
+        if tuple(out.shape) != (N, H, W, 8):
+            raise PmnError("stem_f16s: bad `out` shape")
+    with torch.cuda.device(img.device):
+        check(_lib.lib().pmn_stem_f16s(img.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(), out.data_ptr(),
+                                       N, H, W, _stream(img)), "pmn_stem_f16s")
+    return out
+
+
 def fuse_view(maps: torch.Tensor, ref_slot: int, src_slots: Sequence[int], mats: torch.Tensor, geo_pixel_thres: float,
               geo_depth_thres: float, geo_mask_thres: int, photo_thres: float, want_depth_avg: bool = False,
               want_geo_sum: bool = False, sizes: Optional[Sequence[Tuple[int, int]]] = None):

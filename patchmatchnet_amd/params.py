@@ -277,6 +277,26 @@ def pack_conv_f16s(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS
     return np.ascontiguousarray(out), np.ascontiguousarray(shift.astype(np.float32))
 
 
+def pack_stem_conv1_f16s(weight: torch.Tensor, bn, eps: float = BN_EPS):
+    """FeatureNet conv1 (8 -> 8, 3x3) for pmn_stem_f16s: the weights as the A operands (rows = output channels) of
+    v_mfma_f32_16x16x32_f16 -> (float16 [3 k-steps][2 (hi|lo)][64 lanes][8], float32 shift [8]).  Lane l = 16 kb + row: row = output
+    channel (rows 8..15 zero), k-block q = 4 ks + kb = tap dy * 3 + dx (blocks 9..11 zero), the 8 values = input channels 0..7;
+    BatchNorm scale folded in float64, every weight split with ``split_f16``."""
+    w = _np64(weight)
+    if w.shape != (8, 8, 3, 3):
+        raise ValueError("pack_stem_conv1_f16s: conv1 is 8 -> 8, 3x3")
+    g, b, m, v = (_np64(t) for t in bn)
+    sc = g / np.sqrt(v + eps)
+    w = w * sc[:, None, None, None]
+    shift = b - m * sc
+    full = np.zeros((3, 4, 16, 8), np.float64)  # [ks][kb][row][e]
+    for q in range(9):
+        dy, dx = divmod(q, 3)
+        full[q // 4, q % 4, :8, :] = w[:, :, dy, dx]
+    hi, lo = split_f16(full.reshape(3, 64, 8))
+    return np.ascontiguousarray(np.stack((hi, lo), axis=1)), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

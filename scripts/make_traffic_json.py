@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE passes with
+"""Turns the rocprofv3 --pmc passes of scripts/gpu_pmc_traffic.sh (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE passes with
 --kernel-trace only) into profiles/pmc_traffic.json: HBM bytes per launch of every pmn_warp_correlate kernel shape.
 
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies
@@ -35,9 +35,9 @@ for k, v in vals.items():
         fk = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
         wk = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
         out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-dst = os.path.join(root, "profiles", "pmc_traffic.json")
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_win.sh) over the replay of a real "
-                     "forward's pmn_warp_correlate launches (scripts/warp_tune.py, bench.py's sample, cfg-2)",
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "pmc_traffic.json")
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_traffic.sh) over bench.py --eager: the "
+                     "pmn_warp_correlate launches of real forwards on the bench's samples (cfg-2), averaged per kernel shape",
            "kernel_source_sha256": warp_kernel_source_hash(),
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE under-reports wide reads by 2x)",
            "kernels": out}, open(dst, "w"), indent=1)

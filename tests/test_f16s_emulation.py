@@ -111,3 +111,61 @@ def test_split_keeps_22_bits():
     big = np.abs(x) >= 2e-4  # hi is a NORMAL fp16 number down to 6.1e-5: 22 bits from there up (fp16 overflows at 65504)
     assert (err[big] / np.abs(x[big])).max() < 2.0 ** -21
     assert err[~big].max() < 1e-10  # below that the absolute error is what matters: 2^-24 (fp16 subnormal step) / 2048
+
+
+def test_emulated_stem_conv1_on_the_matrix_cores():
+    """pmn_stem_f16s step (3): conv1 with the roles swapped (A rows = output channels, B columns = pixels), the mid-patch addressing
+    and params.pack_stem_conv1_f16s, against float64; conv0 is taken from torch (the kernel's VALU part is pmn_stem's)."""
+    g = torch.Generator().manual_seed(7)
+    H, W = 21, 35
+    x = torch.rand(1, 3, H, W, generator=g)
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3, torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    bn1 = (torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1, torch.rand(8, generator=g) + 0.5)
+    mid = F.relu(F.conv2d(x, w0, None, 1, 1))                        # [1,8,H,W] fp32 (conv0 + ReLU)
+    w1a, shift = params.pack_stem_conv1_f16s(w1, bn1)
+    assert w1a.shape == (3, 2, 64, 8) and w1a.dtype == np.float16
+    sc = bn1[0].double() / torch.sqrt(bn1[3].double() + params.BN_EPS)
+    want = F.relu(F.conv2d(mid.double(), w1.double() * sc[:, None, None, None], bn1[1].double() - bn1[2].double() * sc, 1, 1))
+    want = want[0].permute(1, 2, 0).numpy()
+    midn = mid[0].permute(1, 2, 0).numpy()
+    lane = np.arange(64)
+    li, kb = lane % 16, lane // 16
+    out = np.zeros((H, W, 8), np.float32)
+    MW = 18
+    for oy0 in range(0, H, 16):
+        for ox0 in range(0, W, 16):
+            patch = np.zeros((MW, MW, 8), np.float32)                # conv0 output on the halo patch, ZERO outside the image
+            for r in range(MW):
+                for q in range(MW):
+                    gy, gx = oy0 - 1 + r, ox0 - 1 + q
+                    if 0 <= gy < H and 0 <= gx < W:
+                        patch[r, q] = midn[gy, gx]
+            ph, pl = params.split_f16(patch)
+            for wv in range(4):
+                accM = np.zeros((4, 16, 16)); accL = np.zeros((4, 16, 16))   # [t][row = cout][col = pixel]
+                for ks in range(3):
+                    q = np.minimum(4 * ks + kb, 8)
+                    dy, dx = q // 3, q % 3
+                    A_hi = np.zeros((16, 32)); A_lo = np.zeros((16, 32))
+                    for e in range(8):
+                        A_hi[li, 8 * kb + e] = w1a[ks, 0, :, e].astype(np.float64)
+                        A_lo[li, 8 * kb + e] = w1a[ks, 1, :, e].astype(np.float64)
+                    for t in range(4):
+                        row = wv * 4 + t + dy
+                        col = li + dx
+                        B_hi = np.zeros((32, 16)); B_lo = np.zeros((32, 16))
+                        for e in range(8):
+                            B_hi[8 * kb + e, li] = ph[row, col, e].astype(np.float64)
+                            B_lo[8 * kb + e, li] = pl[row, col, e].astype(np.float64)
+                        accM[t] += A_hi @ B_hi
+                        accL[t] += A_hi @ B_lo + A_lo @ B_hi
+                for t in range(4):
+                    oy = oy0 + wv * 4 + t
+                    if oy >= H:
+                        continue
+                    v = np.maximum(accM[t] + accL[t] / params.F16S_LO_SCALE + np.pad(shift, (0, 8))[:, None], 0)  # [cout][pixel]
+                    for i in range(16):
+                        if ox0 + i < W:
+                            out[oy, ox0 + i] = v[:8, i]
+    err = np.abs(out - want).max() / np.abs(want).max()
+    assert err < 5e-7, err

@@ -413,6 +413,34 @@ def test_conv_f16_split_against_torch(k, stride, cin, cout, H, W):
     assert err < 1e-6, err
 
 
+@pytest.mark.parametrize("H,W", [(37, 51), (16, 16), (150, 200)])
+def test_stem_kernels_against_torch(H, W):
+    """pmn_stem (conv0 + conv1 on the fp32 VALU) and pmn_stem_f16s (conv1 on the fp16 matrix cores, split operands) vs
+    conv + BatchNorm + ReLU twice in float64 (reference models/net.py:17-19, 51); partial tiles, image borders (conv1 pads conv0's
+    OUTPUT with zeros, not the image), batch 2."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(H)
+    x = torch.rand(2, 3, H, W, generator=gen)
+    w0, w1 = 0.3 * torch.randn(8, 3, 3, 3, generator=gen), 0.2 * torch.randn(8, 8, 3, 3, generator=gen)
+    bns = [(0.5 + torch.rand(8, generator=gen), 0.1 * torch.randn(8, generator=gen), 0.1 * torch.randn(8, generator=gen),
+            0.5 + torch.rand(8, generator=gen)) for _ in range(2)]
+    t = x.double()
+    for w, bn in ((w0, bns[0]), (w1, bns[1])):
+        t = torch.nn.functional.conv2d(t, w.double(), None, 1, 1)
+        t = torch.relu(torch.nn.functional.batch_norm(t, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, 1e-5))
+    ref = t.permute(0, 2, 3, 1)
+    p0 = [torch.from_numpy(a).to(DEV) for a in PP.pack_conv(w0, bn=bns[0])]
+    p1 = [torch.from_numpy(a).to(DEV) for a in PP.pack_conv(w1, bn=bns[1])]
+    p1h = [torch.from_numpy(a).to(DEV) for a in PP.pack_stem_conv1_f16s(w1, bn=bns[1])]
+    got = P.ops.stem(x.to(DEV), *p0, *p1)
+    got_h = P.ops.stem_f16s(x.to(DEV), *p0, *p1h)
+    for name, g in (("stem", got), ("stem_f16s", got_h)):
+        assert tuple(g.shape) == (2, H, W, 8)
+        err = float((g.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-6, (name, err)
+
+
 def test_fpn_level8_matrix_core_form_matches_valu_form():
     """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
     P = _gpu()
