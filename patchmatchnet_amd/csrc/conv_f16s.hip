@@ -222,23 +222,29 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
 // Fused stem on the fp16 matrix cores: conv0 (3 -> 8, fp32 VALU, as pmn_stem) feeds conv1 (8 -> 8: 72 % of the stem's multiplies)
 // as split-operand MFMAs.  reference models/net.py:17-19, 51.
 //
-// Workgroup = 16 x 16 output pixels.  (1) planar 20 x 20 x 3 input patch -> LDS; (2) every thread evaluates conv0 + BatchNorm + ReLU
-// for its pixels of the 18 x 18 halo patch (zero outside the image: conv1 pads conv0's OUTPUT map), splits the 8 channels into hi / lo
+// Workgroup = TS x TS output pixels (TS = 16).  (1) planar (TS+4)^2 x 3 input patch -> LDS; (2) every thread evaluates conv0 + BatchNorm +
+// ReLU for its pixel of the (TS+2)^2 halo patch (zero outside the image: conv1 pads conv0's OUTPUT map), splits the 8 channels into hi / lo
 // fp16 and writes two planes [18][18][8 halves] (16 B per pixel: a ds_read_b128 lane group {pixels i} x {tap q, tap q + 1} touches 16
 // distinct slots or the same address -- brute-forced); (3) conv1 with the ROLES SWAPPED: the MFMA's A operand (rows) = the 8 output
 // channels (rows 8..15 zero), the B operand (columns) = 16 consecutive pixels of one output row, k = (tap, channel): 9 blocks of 8
 // channels = 3 k-steps (3 padding blocks).  D then holds, in lane (pixel i, kb), output channels 4 kb .. 4 kb + 3 of pixel i for kb = 0, 1:
 // one float4 store per lane, 512 contiguous bytes per 16-pixel row of the channels-last output.  Wave w owns output rows 4 w .. 4 w + 3.
 // =================================================================================================================================
+template <int TS>
 __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
                                                           const float* __restrict__ s0, const f16x8* __restrict__ w1A,
                                                           const float* __restrict__ s1, float* __restrict__ out, const int N,
                                                           const int H, const int W) {
-    constexpr int TW = 16, TH = 16, IW = 20, IWP = 21, MW = 18, NTHR = 256;
+    // TS = 16 is what runs.  TS = 14 makes conv0's halo patch 16 x 16 = ONE pixel per thread (with 16 x 16 outputs it is 18 x 18 = 324
+    // pixels: a second pass in which 68 of 256 threads work); the MFMA tile stays 16 pixels wide and the spare columns / rows compute on
+    // whatever the planes hold and are not stored (an MFMA column only sees its own B column).  Measured on one box: 294.7 vs 295.6 us
+    // per six views -- the second pass is not what the kernel waits for -- so the tile that divides 1600 x 1200 stays.
+    constexpr int TW = TS, TH = TS, IW = TS + 4, IWP = IW + 1, MW = TS + 2, MRP = 18, MROWS = 18, NTHR = 256;
+    static_assert(TS == 14 || TS == 16, "tile of 14 or 16 output pixels");
     __shared__ float xin[3 * IW * IWP];
-    __shared__ float4 mid4[2 * MW * MW];  // two planes of MW*MW pixels x 8 halves (16 B)
+    __shared__ float4 mid4[2 * MROWS * MRP];  // two planes of 18 x 18 pixel slots x 8 halves (16 B); MW x MW of them are written
     _Float16* midh = reinterpret_cast<_Float16*>(mid4);
-    _Float16* midl = midh + MW * MW * 8;
+    _Float16* midl = midh + MROWS * MRP * 8;
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
     const cfloat* cs0 = (const cfloat*)s0;
@@ -303,8 +309,8 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
             hi[c] = h;
             lo[c] = (_Float16)((x - (float)h) * PMN_F16S_LO_SCALE);
         }
-        *reinterpret_cast<f16x8*>(midh + m * 8) = hi;
-        *reinterpret_cast<f16x8*>(midl + m * 8) = lo;
+        *reinterpret_cast<f16x8*>(midh + (r * MRP + q) * 8) = hi;
+        *reinterpret_cast<f16x8*>(midl + (r * MRP + q) * 8) = lo;
     }
     __syncthreads();
     // (3) conv1: D[cout][pixel] += W[cout][k] * mid[k][pixel]
@@ -319,12 +325,13 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         int q = 4 * ks + kb;
         q = q < 8 ? q : 8;  // padding blocks 9..11 (zero weights) read tap 8
         const int dy = q / 3, dx = q - dy * 3;
-        const _Float16* pb = midh + ((wave * 4 + dy) * MW + li + dx) * 8;
+        // (rows up to 4*3 + 3 + 2 = 17 and columns up to 15 + 2 = 17: inside the 18 x 18 slots also when MW = 16)
+        const _Float16* pb = midh + ((wave * 4 + dy) * MRP + li + dx) * 8;
         f16x8 bh[4], blo[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            bh[t] = *reinterpret_cast<const f16x8*>(pb + t * MW * 8);
-            blo[t] = *reinterpret_cast<const f16x8*>(pb + t * MW * 8 + MW * MW * 8);
+            bh[t] = *reinterpret_cast<const f16x8*>(pb + t * MRP * 8);
+            blo[t] = *reinterpret_cast<const f16x8*>(pb + t * MRP * 8 + MROWS * MRP * 8);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][0], bh[t], accM[t], 0, 0, 0);
@@ -334,13 +341,13 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][1], bh[t], accL[t], 0, 0, 0);
     }
     // D rows 4 kb + r = output channels: lanes with kb < 2 hold channels [4 kb, 4 kb + 4) of pixel (ox0 + li, oy0 + 4 wave + t)
-    if (kb < 2) {
+    if (kb < 2 && li < TW) {
         const float4 sh = *reinterpret_cast<const float4*>(s1 + 4 * kb);
         const int ox = ox0 + li;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int oy = oy0 + wave * 4 + t;
-            if (oy < H && ox < W) {
+            if (wave * 4 + t < TH && oy < H && ox < W) {
                 float4 v;
                 v.x = fmaxf(accM[t][0] + accL[t][0] * (1.0f / PMN_F16S_LO_SCALE) + sh.x, 0.0f);
                 v.y = fmaxf(accM[t][1] + accL[t][1] * (1.0f / PMN_F16S_LO_SCALE) + sh.y, 0.0f);
@@ -357,8 +364,9 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
 extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0, const void* w1a, const float* s1, float* out,
                              int N, int H, int W, void* stream) {
     if (!img || !w0 || !s0 || !w1a || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
-    const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(stem_f16s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+    constexpr int TS = 16;
+    const int blocks = N * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+    hipLaunchKernelGGL(stem_f16s_kernel<TS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
                        reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
