@@ -1,5 +1,6 @@
 """CPU tests of the callers either side of the hot path: on-disk formats, the sample source, rank sharding (one and several
-scans), the per-scan all-gather (world_size 2 over gloo).  The consistency-fusion arithmetic is in tests/test_fusion_oracle.py
+scans), the per-scan all-gather (world_size 2 over gloo).  These check the code against layouts written down HERE; the same code
+against the REFERENCE's own datasets/ modules and reference-written files is tests/test_reference_io.py.  The consistency-fusion arithmetic is in tests/test_fusion_oracle.py
 (oracle, CPU) and tests/test_fusion_gpu.py (pmn_fuse_view against it)."""
 import os
 
