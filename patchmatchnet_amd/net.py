@@ -281,6 +281,9 @@ class PatchmatchNet(nn.Module):
                 stacked.update({("nhwc", s): t for s, t in f.items()})
             # per-view NCHW-shaped views over the channels-last storage (no copy)
             return [{s: t[i * B:(i + 1) * B].permute(0, 3, 1, 2) for s, t in f.items()} for i in range(len(images))]
+        if self.hip_feature_net and images[0].is_cuda:  # views of different sizes: one HIP FeatureNet pass per image
+            outs = [self.feature.forward_hip(im) for im in images]
+            return [{s: t.permute(0, 3, 1, 2) for s, t in f.items()} for f in outs]
         if self.batch_feature_extraction and same and len(images) > 1:
             f = self.feature(torch.cat(images, dim=0))
             if stacked is not None:

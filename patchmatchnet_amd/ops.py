@@ -127,21 +127,57 @@ def nchw_to_nhwc(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
 
 
 def stack_sources_nhwc(src_features: Sequence[torch.Tensor]) -> torch.Tensor:
-    """List of N source feature maps [B,C,hs,ws] -> one channels-last buffer [N,B,hs,ws,C]."""
+    """List of N source feature maps [B,C,hs,ws] -> one channels-last buffer [N,B,hs,ws,C] (all maps one size; see
+    ``stack_sources_padded`` for source views of different sizes)."""
+    buf, sizes = stack_sources_padded(src_features)
+    if any(sz != sizes[0] for sz in sizes):
+        raise PmnError("all source feature maps of one stage must share a shape (stack_sources_padded handles mixed sizes)")
+    return buf
+
+
+def stack_sources_padded(src_features: Sequence[torch.Tensor]):
+    """List of N source feature maps [B,C,hs_v,ws_v] -> (channels-last buffer [N,B,HS,WS,C] with HS x WS the LARGEST map and every
+    smaller map in the top-left corner of its slice, zeros elsewhere; [(hs_v, ws_v)]).  The reference warps every source view at
+    its own size (models/module.py:130-181: F.grid_sample un-normalises with the source map's size and pads with zeros), so a
+    sample whose images differ in size is legal there; pmn_warp_correlate reads one size per launch, and zero padding IS
+    grid_sample's padding -- the per-view scale is restored on the projection (``rescale_projection_rows``)."""
     if len(src_features) == 0:
         raise PmnError("at least one source view is required")
-    B, C, hs, ws = src_features[0].shape
-    buf = torch.empty((len(src_features), B, hs, ws, C), dtype=torch.float32, device=src_features[0].device)
+    B, C = src_features[0].shape[:2]
+    sizes = [(int(f.shape[2]), int(f.shape[3])) for f in src_features]
+    if any(tuple(f.shape[:2]) != (B, C) for f in src_features):
+        raise PmnError("source feature maps of one stage must share batch size and channels")
+    hs, ws = max(h for h, _ in sizes), max(w for _, w in sizes)
+    mixed = any(sz != (hs, ws) for sz in sizes)
+    alloc = torch.zeros if mixed else torch.empty
+    buf = alloc((len(src_features), B, hs, ws, C), dtype=torch.float32, device=src_features[0].device)
     for i, f in enumerate(src_features):
-        if tuple(f.shape) != (B, C, hs, ws):
-            raise PmnError("all source feature maps of one stage must share a shape")
         v = f.permute(0, 2, 3, 1)
-        if f.is_cuda and f.dtype == torch.float32 and v.is_contiguous():
+        if sizes[i] != (hs, ws):
+            _dev(f.contiguous(), "src_feature")
+            buf[i][:, :sizes[i][0], :sizes[i][1], :].copy_(v)
+        elif f.is_cuda and f.dtype == torch.float32 and v.is_contiguous():
             buf[i].copy_(v)  # an NCHW-shaped view of channels-last storage (the HIP FeatureNet's output): one plain copy, not a
             #                  transpose to NCHW and back (eval.py's encode-once path hands such views over, 5 per stage)
         else:
             nchw_to_nhwc(f.contiguous(), buf[i])
-    return buf
+    return buf, sizes
+
+
+def rescale_projection_rows(rel_proj: torch.Tensor, sizes, padded_hw) -> torch.Tensor:
+    """Relative projections [B,N,4,4] for source maps that sit zero-padded in an HS x WS buffer: the kernel scales the projected
+    position by (WS-1)/(w-1), the reference by (ws_v-1)/(w-1) (normalise with the reference map, un-normalise with the source map:
+    models/module.py:170-181) -- rows 0 / 1 of view v are multiplied by (ws_v-1)/(WS-1) / (hs_v-1)/(HS-1).  Identity (same tensor)
+    when every map has the padded size."""
+    HS, WS = padded_hw
+    if all(sz == (HS, WS) for sz in sizes):
+        return rel_proj
+    out = rel_proj.clone()
+    for v, (h_v, w_v) in enumerate(sizes):
+        if (h_v, w_v) != (HS, WS):
+            out[:, v, 0, :] *= (w_v - 1) / (WS - 1)
+            out[:, v, 1, :] *= (h_v - 1) / (HS - 1)
+    return out.contiguous()
 
 
 def _mlp_dev(t: torch.Tensor, name: str) -> torch.Tensor:

@@ -164,10 +164,11 @@ class Evaluation(nn.Module):
         rel_proj = f.get("rel_proj")
         if ref_nhwc is None:
             ref_nhwc = ops.nchw_to_nhwc(ref_feature.detach())
-        if src_nhwc is None:
-            src_nhwc = ops.stack_sources_nhwc([s.detach() for s in src_features])
         if rel_proj is None:
             rel_proj = ops.relative_projection(src_projs, ref_proj)
+        if src_nhwc is None:  # source views of different sizes (legal in the reference): zero-padded + projection rows rescaled
+            src_nhwc, sizes = ops.stack_sources_padded([s.detach() for s in src_features])
+            rel_proj = ops.rescale_projection_rows(rel_proj, sizes, tuple(src_nhwc.shape[2:4]))
         depth_sample = depth_sample.contiguous()
         cost, vw, argmax, sim = ops.warp_correlate(
             ref_nhwc, src_nhwc, rel_proj.contiguous(), depth_sample, view_weights.contiguous() if have_vw else None,
@@ -300,10 +301,11 @@ class PatchMatch(nn.Module):
             ref_feature = ref_feature.contiguous()
             propa_offsets = self.propa_conv(ref_feature).contiguous() if propagate_any else None
             eval_offsets = self.eval_conv(ref_feature).contiguous()
-        if src_nhwc is None:
-            src_nhwc = ops.stack_sources_nhwc([f.detach() for f in src_features])
         if rel_proj is None:
             rel_proj = ops.relative_projection(src_projs, ref_proj)
+        if src_nhwc is None:  # source views of different sizes (legal in the reference): zero-padded + projection rows rescaled
+            src_nhwc, sizes = ops.stack_sources_padded([f.detach() for f in src_features])
+            rel_proj = ops.rescale_projection_rows(rel_proj, sizes, tuple(src_nhwc.shape[2:4]))
         rel_proj = rel_proj.contiguous()
         depth_min = depth_min.float().contiguous()
         depth_max = depth_max.float().contiguous()

@@ -707,3 +707,64 @@ def test_fullsize_stage_against_oracle(stage, n_src, H, W):
                 assert GU.abs_err(n(rec["view_weights"]), orec["view_weights"]) < 1e-4
         rel = np.abs(n(rec["depth"]) - orec["depth"]) / orec["depth"]
         assert rel.max() < 1e-3, (it, float(rel.max()))
+
+
+@pytest.mark.parametrize("stage", [3, 2])
+def test_source_views_of_different_sizes_against_oracle(stage):
+    """A sample whose source images differ in size from the reference image and from each other -- legal in the reference
+    (models/module.py:130-181 warps every view at its own size; models/net.py:304-318 rounds every image to multiples of 8 on its
+    own) and refused by rounds 1-2.  The source maps sit zero-padded in one buffer and the projection rows carry the per-view scale
+    (ops.stack_sources_padded / rescale_projection_rows); checked against the oracle, which walks every view at its own size."""
+    P = _gpu()
+    _, params, kw = GU.load_case("default")
+    m = P.PatchmatchNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    cfg = O.default_stage_configs(kw["patchmatch_interval_scale"], kw["propagation_range"], kw["patchmatch_iteration"],
+                                  kw["patchmatch_num_sample"], kw["propagate_neighbors"], kw["evaluate_neighbors"])[stage]
+    pm = getattr(m, f"patchmatch_{stage}")
+    C = {3: 64, 2: 32}[stage]
+    h, w = 40, 56
+    sizes = [(40, 56), (32, 48), (48, 72)]
+    gen = torch.Generator().manual_seed(stage)
+    base = torch.nn.functional.avg_pool2d(0.5 * torch.randn(1, C, 64, 96, generator=gen), 5, 1, 2) * 3.0
+    ref = base[:, :, 8:8 + h, 16:16 + w].contiguous()
+    srcs = [torch.nn.functional.interpolate(base[:, :, 8:8 + h, 16 + 2 * i:16 + 2 * i + w], size=sz, mode="bilinear",
+                                            align_corners=True).contiguous() for i, sz in enumerate(sizes)]
+    # cameras: the synthetic rig at the REFERENCE map's resolution; a source map of another size has its intrinsics scaled to it
+    intr, extr = synth.synthetic_cameras(4, h, w)
+    proj = synth.stage_projections(intr, extr, 1.0)  # [1,4,4,4]
+    src_projs = []
+    for v, (hv, wv) in enumerate(sizes):
+        K = intr[0, v + 1].astype(np.float32).copy()
+        K[0] *= wv / w
+        K[1] *= hv / h
+        pr = extr[0, v + 1].astype(np.float32).copy()
+        pr[:3, :4] = K @ extr[0, v + 1, :3, :4].astype(np.float32)
+        src_projs.append(pr[None])
+    dmin, dmax = np.array([425.0], np.float32), np.array([935.0], np.float32)
+    noise = torch.rand(1, 48, h, w, generator=gen)
+    if stage == 3:
+        depth, vw = None, None
+    else:
+        yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        depth = (680.0 + 100.0 * torch.sin(xx / 11.0) * torch.cos(yy / 9.0)).clamp(425.0, 935.0)[None, None].numpy()
+        vw = torch.rand(1, 3, h, w, generator=gen).numpy()
+    dbg = []
+    with torch.no_grad():
+        pm(ref_feature=ref.to(DEV), src_features=[f.to(DEV) for f in srcs], ref_proj=t(proj[:, 0]), src_projs=[t(p_) for p_ in src_projs],
+           depth_min=t(dmin), depth_max=t(dmax), depth=torch.empty(0, device=DEV) if depth is None else t(depth),
+           view_weights=torch.empty(0, device=DEV) if vw is None else t(vw), noise=noise.to(DEV), debug=dbg)
+    torch.cuda.synchronize()
+    import copy
+    one = copy.copy(cfg)
+    one.iterations = 1
+    otr = []
+    O.patchmatch_stage(one, params, ref.numpy(), [f.numpy() for f in srcs], proj[:, 0], src_projs, dmin, dmax, depth, vw,
+                       noise=noise.numpy(), propa_offsets=None if dbg[0]["propa_offsets"] is None else n(dbg[0]["propa_offsets"]),
+                       eval_offsets=n(dbg[0]["eval_offsets"]), trace=otr)
+    assert GU.abs_err(n(dbg[0]["similarity"]), otr[0]["similarity"]) < 1e-4
+    if stage == 3:
+        assert GU.abs_err(n(dbg[0]["view_weights"]), otr[0]["view_weights"]) < 1e-4
+    rel = np.abs(n(dbg[0]["depth"]) - otr[0]["depth"]) / otr[0]["depth"]
+    assert rel.max() < 1e-3, float(rel.max())
