@@ -16,6 +16,8 @@ Outputs (committed):
   evaluation_io.npz        Evaluation.forward at its own boundary (models/patchmatch.py:145-239): the reference's grid / weight /
                            depth_sample / view_weights inputs and (depth, score, view_weights) outputs of stage-3 iteration 1
                            (PixelwiseNet) and stage-2 iteration 1 of the default cascade (``--only evaluation`` writes just this).
+  cascade_mixed_sizes.npz  a sample whose two source images differ in size from the reference image and from each other
+                           (96x128 / 80x112 / 96x144): the reference's depth, confidence and stage depths (``--only mixed``).
   cfg2_scene.npz           BASELINE configs[1] at FULL size (1600x1200, N=5, iters 1,2,2) on the photo-consistent scene of
                            tests/synth.py (``render_scene``, seed 0; stage-3 noise seed 1234): the reference's final depth,
                            confidence, every stage / iteration depth, stage-3 view weights and the integer confidence index,
@@ -118,6 +120,40 @@ def dump_scene(path, model, n_views=6, H=1200, W=1600, scene_seed=0, noise_seed=
           % (np.median(err), np.quantile(err, 0.9)))
 
 
+MIXED_SIZES = [(96, 128), (80, 112), (96, 144)]  # (H, W) of the reference view and the two source views
+
+
+def mixed_size_inputs():
+    """Seeded sample whose images differ in size (all multiples of 8): cameras of the synthetic rig at 96x128, every view's intrinsics
+    scaled to its own image size (what datasets/mvs.py:84-85 does after a per-image down-scale)."""
+    import synth
+    H0, W0 = MIXED_SIZES[0]
+    intr, extr = synth.synthetic_cameras(len(MIXED_SIZES), H0, W0)
+    intr = intr.copy()
+    imgs = []
+    for v, (H, W) in enumerate(MIXED_SIZES):
+        imgs.append(synth.synthetic_images(len(MIXED_SIZES), H, W)[v])
+        intr[0, v, 0] *= W / W0
+        intr[0, v, 1] *= H / H0
+    noise = torch.rand(1, 48, H0 // 8, W0 // 8, generator=torch.Generator().manual_seed(77))
+    return imgs, intr, extr, np.array([425.0], np.float32), np.array([935.0], np.float32), noise
+
+
+def dump_mixed(path, model):
+    """The reference on a sample with source images of other sizes than the reference image (legal: models/module.py:130-181 warps
+    every view at its own size): final depth, confidence, stage depths.  Inputs regenerate from seeds (``mixed_size_inputs``)."""
+    imgs, intr, extr, dmin, dmax, noise = mixed_size_inputs()
+    depth, conf, dpm, tr = refutil.trace_reference_forward(
+        model, [i.clone() for i in imgs], torch.from_numpy(intr).clone(), torch.from_numpy(extr).clone(),
+        torch.from_numpy(dmin), torch.from_numpy(dmax), noise)
+    out = {"depth": t2n(depth), "confidence": t2n(conf)}
+    for s in (1, 2, 3):
+        for it, d in enumerate(dpm[s]):
+            out[f"s{s}_it{it + 1}_depth_out"] = t2n(d)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
 def dump_ops(path):
     _, _, ref_module = refutil.import_reference()
     g = torch.Generator().manual_seed(7)
@@ -151,6 +187,9 @@ def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "evaluation":
         dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
         return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "mixed":
+        dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "scene":
         dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
         return
@@ -181,6 +220,7 @@ def main():
     dump_ops(os.path.join(HERE, "ops_small.npz"))
     dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
     dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
+    dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
 
 
 if __name__ == "__main__":

@@ -768,3 +768,34 @@ def test_source_views_of_different_sizes_against_oracle(stage):
         assert GU.abs_err(n(dbg[0]["view_weights"]), otr[0]["view_weights"]) < 1e-4
     rel = np.abs(n(dbg[0]["depth"]) - otr[0]["depth"]) / otr[0]["depth"]
     assert rel.max() < 1e-3, float(rel.max())
+
+
+def test_forward_with_images_of_different_sizes_against_the_reference():
+    """PatchmatchNet.forward on a sample whose source images are smaller / larger than the reference image, against the REFERENCE's
+    own output on the same sample (tests/golden/cascade_mixed_sizes.npz, make_golden.py --only mixed; reference models/net.py:176-301
+    with per-view FeatureNet passes and per-view warps)."""
+    P = _gpu()
+    g, params, kw = GU.load_npz("cascade_mixed_sizes.npz"), GU.load_npz("params_000007.npz"), GU.CASES["default"][2]
+    # the inputs regenerate from seeds (same generator as the golden script, restated here: no reference import on the GPU box)
+    sizes = [(96, 128), (80, 112), (96, 144)]
+    intr, extr = synth.synthetic_cameras(3, 96, 128)
+    intr = intr.copy()
+    imgs = []
+    for v, (H, W) in enumerate(sizes):
+        imgs.append(synth.synthetic_images(3, H, W)[v].to(DEV))
+        intr[0, v, 0] *= W / 128
+        intr[0, v, 1] *= H / 96
+    noise = torch.rand(1, 48, 12, 16, generator=torch.Generator().manual_seed(77)).to(DEV)
+    m = P.PatchmatchNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        depth, conf, dpm = m(imgs, t(intr), t(extr), t(np.array([425.0], np.float32)), t(np.array([935.0], np.float32)), noise=noise)
+    assert tuple(depth.shape) == (1, 1, 96, 128)
+    for st in (3, 2, 1):
+        for it, d in enumerate(dpm[st]):
+            rel = np.abs(n(d) - g[f"s{st}_it{it + 1}_depth_out"]) / g[f"s{st}_it{it + 1}_depth_out"]
+            assert np.quantile(rel, 0.999) < 1e-3 and rel.max() < 2e-2, (st, it, float(rel.max()))
+    rel = np.abs(n(depth) - g["depth"]) / g["depth"]
+    assert float(np.quantile(rel, 0.999)) < 1e-3, float(np.quantile(rel, 0.999))
+    assert float((np.abs(n(conf) - g["confidence"]) > 1e-3).mean()) < 1e-2
