@@ -205,8 +205,11 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     a.Ho = (H - 1) / (stride > 0 ? stride : 1) + 1;
     a.Wo = (W - 1) / (stride > 0 ? stride : 1) + 1;
     hipStream_t st = (hipStream_t)stream;
-    // Tile / chunk shapes from a same-box A/B of three build variants (profiles/r03_f16s_ab.log): small chunks (more workgroups per
-    // CU) win where the layer is latency-bound, M = 32 pixels per wave (MT = 2) where the accumulators cap the occupancy.
+    // Tile / chunk shapes from same-box A/Bs of build variants (profiles/r03_f16s_ab.log): small chunks (more workgroups per CU) and
+    // M = 32 pixels per wave (MT = 2) win on the small layers; M = 16 loses (the B operands are re-read per wave), and so does a
+    // persistent variant that prefetches the next (tile, chunk) behind the MFMAs with the B operands staged in LDS
+    // (scripts/experiments/conv_f16s_persistent_prefetch.hip.txt: correct, 5-10 % slower) -- these layers are bound by operand delivery
+    // (8 KB of B operands per 384 MFMA cycles and wave = 85 B/clk/CU against the L1's 64), not by the latency of the patch loads.
     //                                                            CIN COUT KS S  CC CCP MT WPS
     if (k == 3 && stride == 1 && cin == 16 && cout == 16) return launch_f16s<16, 16, 3, 1, 16, 16, 4, 4>(in, weights, shift, out, a, st);
     if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 16, 16, 2, 4>(in, weights, shift, out, a, st);
