@@ -460,6 +460,10 @@ def main():
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
                                    f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
                        "distinct_samples": len(samples),
+                       "arithmetic": "fp32 results throughout; FeatureNet's conv1..conv10 run on the fp16 matrix cores with SPLIT operands "
+                                     "(x = hi + lo/2048, three exact-product MFMAs, fp32 accumulation): 2-4e-7 of the output scale, the error of "
+                                     "an fp32 convolution (tests/test_f16s_emulation.py, tests/test_hip_parity.py); model.feature.f16_split = False "
+                                     "selects the fp32 Winograd / fp32 MFMA kernels",
                        "scene": "photo-consistent rendered surface (tests/synth.render_scene), one texture seed per sample"
                                 if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
