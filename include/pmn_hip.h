@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 14
+#define PMN_ABI_VERSION 15
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -176,6 +176,15 @@ int pmn_conv5x5s2_wino(const float *in, const float *weights, const float *shift
  * [N,(H-1)/stride+1,(W-1)/stride+1,cout] float32 (padding k/2). */
 int pmn_conv2d_f16s(const float *in, const void *weights, const float *shift, float *out, int N, int H, int W, int cin, int cout,
                     int k, int stride, int relu, void *stream);
+
+/* The offset heads of one PatchMatch stage -- propa_conv rows first, then eval_conv (reference models/patchmatch.py:288-311, :467, :471) --
+ * as ONE dilated 3x3 convolution with bias on the fp16 matrix cores with split operands (see pmn_conv2d_f16s), planar outputs.
+ * in [N,H,W,cin] channels-last; weights DEVICE float16 [cin/16][k-steps][coutp/16][2][64][8] with coutp = cout rounded up to 16
+ * (patchmatchnet_amd/params.py pack_offset_heads_f16s); shift DEVICE float[coutp]; out_a [N,ca,H,W] = channels [0,ca), out_b
+ * [N,cout-ca,H,W] = the rest (NULL when ca == cout).  Supported (cin, dilation): (64,2), (32,4), (16,6) -- the reference's three stages
+ * -- with cout <= 64; PMN_ERR_SHAPE otherwise (the caller then uses pmn_conv2d_mfma / pmn_conv2d). */
+int pmn_offset_heads_f16s(const float *in, const void *weights, const float *shift, float *out_a, float *out_b, int N, int H, int W,
+                          int cin, int cout, int ca, int dil, void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

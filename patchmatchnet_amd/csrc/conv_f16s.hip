@@ -31,16 +31,21 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct F16sArgs {
     int N, H, W, Ho, Wo, relu;
+    int cout, ca;   // OUTMODE 1 / 2: valid output channels (the operands are padded to COUT = a multiple of 16), channels of `out`
+    float* out_b;   // OUTMODE 1 / 2: channels [ca, cout) go here
 };
 
 #define PMN_F16S_LO_SCALE 2048.0f
 
-template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS>
+// DIL = dilation (padding DIL * (KS / 2)); OUTMODE 0: out [N,Ho,Wo,COUT] channels-last; 1: planar, split: out [N,ca,Ho,Wo] | out_b
+// [N,cout-ca,Ho,Wo] (the offset heads of a PatchMatch stage: propa_conv rows, then eval_conv rows); 2: channels-last, split.
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0>
 __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __restrict__ in, const f16x8* __restrict__ wB,
                                                              const float* __restrict__ shift, float* __restrict__ out,
                                                              const F16sArgs a) {
     constexpr int NT = COUT / 16, NCB = CC / 8, CHUNKS = CIN / CC, NQ = KS * KS * NCB, KSTEPS = (NQ + 3) / 4;
-    constexpr int TH = 4 * MT, TW = 16, PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PAD = KS / 2;
+    constexpr int TH = 4 * MT, TW = 16, PH = (TH - 1) * S + (KS - 1) * DIL + 1, PW = (TW - 1) * S + (KS - 1) * DIL + 1;
+    constexpr int PAD = DIL * (KS / 2);
     constexpr int PLANE = PH * PW * CCP;  // halves per plane
     constexpr int NTHR = 256;
     static_assert(CCP % 8 == 0 && CC % 8 == 0 && CIN % CC == 0, "16-byte aligned channel blocks");
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
             if (4 * ks + 3 >= NQ) q = q < NQ - 1 ? q : NQ - 1;
             const int tap = q / NCB, cb = q - tap * NCB;
             const int dy = tap / KS, dx = tap - dy * KS;
-            const _Float16* pa = Phi + ((wave * MT * S + dy) * PW + li * S + dx) * CCP + cb * 8;
+            const _Float16* pa = Phi + ((wave * MT * S + dy * DIL) * PW + li * S + dx * DIL) * CCP + cb * 8;
             f16x8 ah[MT], al[MT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
@@ -164,29 +169,59 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
         }
     }
 
-    // ---- epilogue: main + low / 2048 + shift (folded BatchNorm), ReLU; lane = output channel 16 nt + li, rows 4 kb + r = pixels
+    // ---- epilogue: main + low / 2048 + shift (folded BatchNorm / bias), ReLU; lane = output channel 16 nt + li, rows 4 kb + r = pixels
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float sh = shift[nt * 16 + li];
+        const int c = nt * 16 + li;
+        const float sh = shift[c];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int oy = oy0 + wave * MT + t;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ox = ox0 + 4 * kb + r;
-                float v = accM[t][nt][r] + accL[t][nt][r] * (1.0f / PMN_F16S_LO_SCALE) + sh;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + nt * 16 + li] = v;
+                v[r] = accM[t][nt][r] + accL[t][nt][r] * (1.0f / PMN_F16S_LO_SCALE) + sh;
+                if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+            }
+            if constexpr (OUTMODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ox = ox0 + 4 * kb + r;
+                    if (oy < a.Ho && ox < a.Wo) out[(((size_t)n * a.Ho + oy) * a.Wo + ox) * COUT + c] = v[r];
+                }
+            } else {
+                if (c < a.cout && oy < a.Ho) {
+                    const bool first = c < a.ca;
+                    float* dst = first ? out : a.out_b;
+                    const int cx = first ? c : c - a.ca, nc = first ? a.ca : a.cout - a.ca;
+                    if constexpr (OUTMODE == 1) {  // planar: the lane's four pixels are consecutive in x
+                        float* row = dst + (((size_t)n * nc + cx) * a.Ho + oy) * a.Wo;
+                        const int ox = ox0 + 4 * kb;
+                        if ((a.Wo & 3) == 0 && ox + 3 < a.Wo) {
+                            *reinterpret_cast<float4*>(row + ox) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (ox + r < a.Wo) row[ox + r] = v[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ox = ox0 + 4 * kb + r;
+                            if (ox < a.Wo) dst[(((size_t)n * a.Ho + oy) * a.Wo + ox) * nc + cx] = v[r];
+                        }
+                    }
+                }
             }
         }
     }
 }
 
-template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS>
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0>
 static int launch_f16s(const float* in, const void* w, const float* shift, float* out, F16sArgs a, hipStream_t st) {
-    constexpr int TH = 4 * MT, PH = (TH - 1) * S + KS, PW = 15 * S + KS;
+    constexpr int TH = 4 * MT, PH = (TH - 1) * S + (KS - 1) * DIL + 1, PW = 15 * S + (KS - 1) * DIL + 1;
     const size_t lds = (size_t)2 * PH * PW * CCP * sizeof(_Float16);
-    auto kern = conv_f16s_kernel<CIN, COUT, KS, S, CC, CCP, MT, WPS>;
+    auto kern = conv_f16s_kernel<CIN, COUT, KS, S, CC, CCP, MT, WPS, DIL, OUTMODE>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f16x8*>(w), shift, out, a);
@@ -202,6 +237,7 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     if (!in || !weights || !shift || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
     F16sArgs a;
     a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.cout = cout; a.ca = cout; a.out_b = nullptr;
     a.Ho = (H - 1) / (stride > 0 ? stride : 1) + 1;
     a.Wo = (W - 1) / (stride > 0 ? stride : 1) + 1;
     hipStream_t st = (hipStream_t)stream;
@@ -220,6 +256,35 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     return PMN_ERR_SHAPE;
 }
 
+
+// The offset heads of one PatchMatch stage (propa_conv rows first, then eval_conv: reference models/patchmatch.py:288-311) as ONE dilated
+// 3x3 convolution with bias on the fp16 matrix cores (split operands), planar outputs.  in [N,H,W,cin] channels-last; weights DEVICE
+// fp16 [cin/16][k-steps][coutp/16][2][64][8] (params.pack_conv_f16s_general, rows padded with zeros to coutp = a multiple of 16); shift
+// DEVICE float[coutp]; out_a [N,ca,H,W], out_b [N,cout-ca,H,W] (may be NULL when ca == cout).  Supported: (cin, dilation) in
+// {(64,2), (32,4), (16,6)} = the reference's stages 3, 2, 1 with coutp in {32, 48, 64}; everything else: PMN_ERR_SHAPE (the caller
+// falls back to pmn_conv2d_mfma / pmn_conv2d).
+template <int CIN, int DIL, int MT, int WPS>
+static int dispatch_heads(const float* in, const void* w, const float* shift, float* out_a, int coutp, F16sArgs a, hipStream_t st) {
+    if (coutp == 32) return launch_f16s<CIN, 32, 3, 1, 16, 16, MT, WPS, DIL, 1>(in, w, shift, out_a, a, st);
+    if (coutp == 48) return launch_f16s<CIN, 48, 3, 1, 16, 16, MT, WPS, DIL, 1>(in, w, shift, out_a, a, st);
+    if (coutp == 64) return launch_f16s<CIN, 64, 3, 1, 16, 16, MT, (WPS > 3 ? 3 : WPS), DIL, 1>(in, w, shift, out_a, a, st);
+    return PMN_ERR_SHAPE;
+}
+
+extern "C" int pmn_offset_heads_f16s(const float* in, const void* weights, const float* shift, float* out_a, float* out_b, int N, int H,
+                                     int W, int cin, int cout, int ca, int dil, void* stream) {
+    if (!in || !weights || !shift || !out_a || N < 1 || H < 1 || W < 1 || cout < 1 || ca < 1 || ca > cout) return PMN_ERR_ARG;
+    if (ca < cout && !out_b) return PMN_ERR_ARG;
+    F16sArgs a;
+    a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.relu = 0;
+    a.cout = cout; a.ca = ca; a.out_b = out_b;
+    const int coutp = (cout + 15) / 16 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 64 && dil == 2) return dispatch_heads<64, 2, 2, 3>(in, weights, shift, out_a, coutp, a, st);
+    if (cin == 32 && dil == 4) return dispatch_heads<32, 4, 2, 4>(in, weights, shift, out_a, coutp, a, st);
+    if (cin == 16 && dil == 6) return dispatch_heads<16, 6, 2, 4>(in, weights, shift, out_a, coutp, a, st);
+    return PMN_ERR_SHAPE;
+}
 
 // =================================================================================================================================
 // Fused stem on the fp16 matrix cores: conv0 (3 -> 8, fp32 VALU, as pmn_stem) feeds conv1 (8 -> 8: 72 % of the stem's multiplies)

@@ -541,6 +541,29 @@ def offset_heads_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tenso
     return out_a, out_b
 
 
+F16S_HEAD_SHAPES = {(64, 2), (32, 4), (16, 6)}  # (input channels, dilation) of the reference's stages 3, 2, 1
+
+
+def offset_heads_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int, dil: int):
+    """pmn_offset_heads_f16s: the offset heads of one stage (propa_conv rows first, then eval_conv; reference
+    models/patchmatch.py:288-311) as one dilated 3x3 convolution with bias on the fp16 matrix cores (split operands);
+    x [N,H,W,cin] channels-last, weights / shift from params.pack_offset_heads_f16s -> ([N,ca,H,W], [N,cout-ca,H,W] or None) planar."""
+    _dev(x, "x")
+    _dev(shift, "shift")
+    N, H, W, cin = x.shape
+    coutp = shift.shape[0]
+    if not isinstance(weights, torch.Tensor) or not weights.is_cuda or weights.dtype != torch.float16 or not weights.is_contiguous() \
+            or tuple(weights.shape) != (cin // 16, (9 * 2 + 3) // 4, coutp // 16, 2, 64, 8) or not 0 < ca <= cout <= coutp \
+            or coutp != (cout + 15) // 16 * 16:
+        raise PmnError("offset_heads_f16s: weights are not in pack_offset_heads_f16s layout for this input")
+    out_a = torch.empty((N, ca, H, W), dtype=torch.float32, device=x.device)
+    out_b = torch.empty((N, cout - ca, H, W), dtype=torch.float32, device=x.device) if ca < cout else None
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_offset_heads_f16s(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out_a.data_ptr(), _ptr(out_b), N,
+                                               H, W, cin, cout, ca, dil, _stream(x)), "pmn_offset_heads_f16s")
+    return out_a, out_b
+
+
 def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, ca: int):
     """pmn_fpn_level: one level of the folded FPN head, out = bilinear_x2(u) + b + x @ w (reference models/net.py:57-67 with
     the 1x1 convolutions composed, params.fold_fpn).  x [N,H,W,cin], u [N,H/2,W/2,cout] or None, w [cin,cout], b [cout]

@@ -239,6 +239,25 @@ def split_f16(x: np.ndarray):
     return hi, lo
 
 
+def _pack_f16s(w: np.ndarray, CC: int) -> np.ndarray:
+    """[cout (multiple of 16), cin, K, K] float64 -> float16 [cin/CC, k-steps, cout/16, 2, 64, 8] in B-operand lane order (see
+    ``pack_conv_f16s``)."""
+    cout, cin, K, _ = w.shape
+    ncb, chunks, nt = CC // 8, cin // CC, cout // 16
+    nq = K * K * ncb
+    ksteps = (nq + 3) // 4
+    full = np.zeros((chunks, ksteps * 4, cout, 8), np.float64)  # [chunk][q][cout][e]
+    for ch in range(chunks):
+        for q in range(nq):
+            tap, cb = divmod(q, ncb)
+            dy, dx = divmod(tap, K)
+            full[ch, q] = w[:, ch * CC + 8 * cb:ch * CC + 8 * cb + 8, dy, dx]
+    # [chunk][ks][kb][nt][n][e] -> [chunk][ks][nt][kb][n][e]: lane = 16 kb + n
+    full = full.reshape(chunks, ksteps, 4, nt, 16, 8).transpose(0, 1, 3, 2, 4, 5).reshape(chunks, ksteps, nt, 64, 8)
+    hi, lo = split_f16(full)
+    return np.ascontiguousarray(np.stack((hi, lo), axis=3))  # [chunk][ks][nt][split][lane][8]
+
+
 def pack_conv_f16s(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS):
     """Conv2d weight [cout,cin,K,K] (3x3 stride 1 or 5x5 stride 2; cin in {8,16,32,64}, cout in {16,32,64}) (+ BatchNorm2d tensors or
     a conv bias) -> (float16 [chunks, ksteps, cout/16, 2, 64, 8], float32 [cout]) for pmn_conv2d_f16s: the B operands of
@@ -260,21 +279,23 @@ def pack_conv_f16s(weight: torch.Tensor, bn=None, bias=None, eps: float = BN_EPS
         shift = _np64(bias)
     else:
         shift = np.zeros(cout)
-    CC = f16s_chunk(cin, K)
-    ncb, chunks, nt = CC // 8, cin // CC, cout // 16
-    nq = K * K * ncb
-    ksteps = (nq + 3) // 4
-    full = np.zeros((chunks, ksteps * 4, cout, 8), np.float64)  # [chunk][q][cout][e]
-    for ch in range(chunks):
-        for q in range(nq):
-            tap, cb = divmod(q, ncb)
-            dy, dx = divmod(tap, K)
-            full[ch, q] = w[:, ch * CC + 8 * cb:ch * CC + 8 * cb + 8, dy, dx]
-    # [chunk][ks][kb][nt][n][e] -> [chunk][ks][nt][kb][n][e]: lane = 16 kb + n
-    full = full.reshape(chunks, ksteps, 4, nt, 16, 8).transpose(0, 1, 3, 2, 4, 5).reshape(chunks, ksteps, nt, 64, 8)
-    hi, lo = split_f16(full)
-    out = np.stack((hi, lo), axis=3)  # [chunk][ks][nt][split][lane][8]
-    return np.ascontiguousarray(out), np.ascontiguousarray(shift.astype(np.float32))
+    return _pack_f16s(w, f16s_chunk(cin, K)), np.ascontiguousarray(shift.astype(np.float32))
+
+
+def pack_offset_heads_f16s(weight: torch.Tensor, bias: torch.Tensor):
+    """The row-concatenated 3x3 filters [cout,cin,3,3] and biases of a stage's offset heads (propa_conv rows, then eval_conv:
+    reference models/patchmatch.py:288-311) for pmn_offset_heads_f16s: rows zero-padded to a multiple of 16, chunks of 16 input
+    channels -> (float16 [cin/16, k-steps, coutp/16, 2, 64, 8], float32 [coutp])."""
+    w = _np64(weight)
+    cout, cin, K, _ = w.shape
+    if K != 3 or cin % 16:
+        raise ValueError("pack_offset_heads_f16s: 3x3 filters over a multiple of 16 input channels")
+    coutp = (cout + 15) // 16 * 16
+    wp = np.zeros((coutp, cin, 3, 3), np.float64)
+    wp[:cout] = w
+    shift = np.zeros(coutp, np.float64)
+    shift[:cout] = _np64(bias)
+    return _pack_f16s(wp, 16), np.ascontiguousarray(shift.astype(np.float32))
 
 
 def pack_stem_conv1_f16s(weight: torch.Tensor, bn, eps: float = BN_EPS):

@@ -235,6 +235,8 @@ class PatchMatch(nn.Module):
         # offset heads through pmn_conv2d (True) or MIOpen (False)
         self.hip_offset_heads = True
         self.mfma_offset_heads = True  # ... and on the matrix cores (pmn_conv2d_mfma, both heads in one launch) when supported
+        self.f16_split_heads = True  # ... on the FP16 matrix cores with split operands (pmn_offset_heads_f16s) for the reference's
+        #                              three (channels, dilation) combinations; fp32-convolution accuracy (csrc/conv_f16s.hip)
         self._heads = None
         self._heads_key = None
         self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
@@ -257,6 +259,9 @@ class PatchMatch(nn.Module):
                     if wcat.shape[0] <= 64:
                         w, s = params.pack_conv_mfma(wcat, bias=bcat)
                         pk["mfma_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                        if (self.eval_conv.in_channels, self.dilation) in ops.F16S_HEAD_SHAPES:
+                            w, s = params.pack_offset_heads_f16s(wcat, bcat)
+                            pk["f16s_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             self._heads, self._heads_key = pk, key
         return self._heads
 
@@ -288,7 +293,12 @@ class PatchMatch(nn.Module):
             # offset heads as HIP convolutions on the channels-last reference feature, planar [B,2K,h,w] output
             pk = self._packed_heads()
             key = "mfma_both" if propagate_any else "mfma_eval_only"
-            if self.mfma_offset_heads and key in pk:
+            fkey = "f16s_both" if propagate_any else "f16s_eval_only"
+            if self.f16_split_heads and fkey in pk:  # fp16 matrix cores, split operands (round 3)
+                n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
+                a_, b_ = ops.offset_heads_f16s(ref_nhwc, *pk[fkey], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
+                propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)
+            elif self.mfma_offset_heads and key in pk:
                 n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
                 a_, b_ = ops.offset_heads_mfma(ref_nhwc, *pk[key], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
                 propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)

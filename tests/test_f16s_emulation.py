@@ -14,16 +14,16 @@ from patchmatchnet_amd import params
 LAYERS = [(5, 2, 8, 16), (3, 1, 16, 16), (5, 2, 16, 32), (3, 1, 32, 32), (5, 2, 32, 64), (3, 1, 64, 64)]  # (K, stride, cin, cout)
 
 
-def emulate(x_nhwc, wpk, shift, K, S, cin, cout, relu=True):
-    """The kernel, wave by wave: x [N,H,W,cin] float32 -> [N,Ho,Wo,cout] float32."""
+def emulate(x_nhwc, wpk, shift, K, S, cin, cout, relu=True, dil=1, CC=None):
+    """The kernel, wave by wave: x [N,H,W,cin] float32 -> [N,Ho,Wo,cout] float32 (cout = the padded channel count)."""
     N, H, W, _ = x_nhwc.shape
-    pad = K // 2
+    pad = dil * (K // 2)
     Ho, Wo = (H - 1) // S + 1, (W - 1) // S + 1
-    CC = params.f16s_chunk(cin, K)
+    CC = CC or params.f16s_chunk(cin, K)
     ncb, chunks, NT = CC // 8, cin // CC, cout // 16
     MT = 4 if S == 1 else 2
     TH, TW = 4 * MT, 16
-    PH, PW = (TH - 1) * S + K, (TW - 1) * S + K
+    PH, PW = (TH - 1) * S + (K - 1) * dil + 1, (TW - 1) * S + (K - 1) * dil + 1
     nq = K * K * ncb
     ksteps = (nq + 3) // 4
     assert wpk.shape == (chunks, ksteps, NT, 2, 64, 8)
@@ -51,8 +51,8 @@ def emulate(x_nhwc, wpk, shift, K, S, cin, cout, relu=True):
                             tap, cb = q // ncb, q % ncb
                             dy, dx = tap // K, tap % K
                             for t in range(MT):
-                                row = (wv * MT + t) * S + dy
-                                col = li * S + dx
+                                row = (wv * MT + t) * S + dy * dil
+                                col = li * S + dx * dil
                                 a_hi = phi[row, col][np.arange(64)[:, None], (cb * 8)[:, None] + np.arange(8)[None]].astype(np.float64)
                                 a_lo = plo[row, col][np.arange(64)[:, None], (cb * 8)[:, None] + np.arange(8)[None]].astype(np.float64)
                                 A_hi = np.zeros((16, 32)); A_lo = np.zeros((16, 32))
@@ -168,4 +168,22 @@ def test_emulated_stem_conv1_on_the_matrix_cores():
                         if ox0 + i < W:
                             out[oy, ox0 + i] = v[:8, i]
     err = np.abs(out - want).max() / np.abs(want).max()
+    assert err < 5e-7, err
+
+
+@pytest.mark.parametrize("cin,dil,n_p,n_e", [(64, 2, 32, 18), (32, 4, 16, 18), (16, 6, 0, 18)])
+def test_emulated_offset_heads(cin, dil, n_p, n_e):
+    """pmn_offset_heads_f16s: dilated taps, output rows zero-padded to a multiple of 16 (params.pack_offset_heads_f16s), bias, no ReLU."""
+    g = torch.Generator().manual_seed(cin + dil)
+    H, W = 19, 35
+    x = torch.randn(1, cin, H, W, generator=g)
+    cout = n_p + n_e
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    wpk, shift = params.pack_offset_heads_f16s(w, b)
+    coutp = (cout + 15) // 16 * 16
+    assert wpk.shape == (cin // 16, 5, coutp // 16, 2, 64, 8) and shift.shape == (coutp,)
+    got = emulate(x.permute(0, 2, 3, 1).contiguous().numpy(), wpk, shift, 3, 1, cin, coutp, relu=False, dil=dil, CC=16)[..., :cout]
+    want = F.conv2d(x.double(), w.double(), b.double(), 1, dil, dil).permute(0, 2, 3, 1).numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
     assert err < 5e-7, err

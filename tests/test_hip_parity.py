@@ -335,6 +335,31 @@ def test_offset_heads_mfma_against_torch(cin, dil, n_p, n_e, H, W, N):
         assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,dil,n_p,n_e", [(64, 2, 32, 18), (64, 2, 0, 18), (32, 4, 16, 18), (32, 4, 8, 34), (16, 6, 0, 18),
+                                             (16, 6, 8, 18), (16, 6, 16, 34)])
+@pytest.mark.parametrize("H,W,N", [(37, 50, 2), (16, 16, 1), (40, 52, 1)])
+def test_offset_heads_f16_split_against_torch(cin, dil, n_p, n_e, H, W, N):
+    """pmn_offset_heads_f16s: propa_conv + eval_conv of a stage as one dilated 3x3 convolution with bias on the fp16 matrix cores
+    (split operands) vs F.conv2d (float64) per head: ragged tiles, widths with and without the float4 store path, batch > 1,
+    zero-padded output rows (18 / 34 / 50 channels)."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(cin + dil + n_p + H)
+    x = torch.randn(N, cin, H, W, generator=gen)
+    heads = [(0.1 * torch.randn(c, cin, 3, 3, generator=gen), 0.1 * torch.randn(c, generator=gen)) for c in (n_p, n_e) if c]
+    wcat, bcat = torch.cat([w for w, _ in heads], 0), torch.cat([b for _, b in heads], 0)
+    w, sh = PP.pack_offset_heads_f16s(wcat, bcat)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ca = n_p if n_p else n_e
+    a, b = P.ops.offset_heads_f16s(xin, torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), n_p + n_e, ca, dil)
+    outs = [a] if b is None else [a, b]
+    assert len(outs) == len(heads)
+    for got, (wt, bias) in zip(outs, heads):
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), 1, dil, dil)
+        assert tuple(got.shape) == tuple(ref.shape) and got.is_contiguous()
+        assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize("C", [16, 32, 64])
 @pytest.mark.parametrize("H,W", [(37, 51), (8, 16), (150, 200)])
 def test_conv3x3_winograd_against_torch(C, H, W):
