@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 16
+#define PMN_ABI_VERSION 15
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -185,13 +185,6 @@ int pmn_conv2d_f16s(const float *in, const void *weights, const float *shift, fl
  * -- with cout <= 64; PMN_ERR_SHAPE otherwise (the caller then uses pmn_conv2d_mfma / pmn_conv2d). */
 int pmn_offset_heads_f16s(const float *in, const void *weights, const float *shift, float *out_a, float *out_b, int N, int H, int W,
                           int cin, int cout, int ca, int dil, void *stream);
-
-/* 1x1 convolution with bias whose output channels are split between two channels-last tensors, on the fp16 matrix cores with split
- * operands: the 1/8-resolution level of the composed FPN head (reference models/net.py:57-67; patchmatchnet_amd/params.py fold_fpn).
- * in [N,H,W,cin]; weights DEVICE float16 [cin/32][1][cout/16][2][64][8] (params.pack_pointwise_f16s); shift DEVICE float[cout];
- * out_a [N,H,W,ca], out_b [N,H,W,cout-ca].  Supported: cin = 64, cout = 112. */
-int pmn_pointwise_f16s(const float *in, const void *weights, const float *shift, float *out_a, float *out_b, int N, int H, int W, int cin,
-                       int cout, int ca, void *stream);
 
 /* One level of FeatureNet's FPN head in FOLDED form (reference models/net.py:57-67).  The head is linear (1x1 convolutions,
  * bilinear x2 up-sampling, sums), so output_k(upsample(intra) + inner_k(conv)) is evaluated as

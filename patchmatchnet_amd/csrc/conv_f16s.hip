@@ -286,21 +286,6 @@ extern "C" int pmn_offset_heads_f16s(const float* in, const void* weights, const
     return PMN_ERR_SHAPE;
 }
 
-// 1x1 convolution with bias, output channels split between two channels-last tensors, on the fp16 matrix cores (split operands): the
-// 1/8-resolution level of the folded FPN head, [f3 | u8] = W8 . conv10 + b8 (reference models/net.py:57-67 composed by params.fold_fpn).
-// in [N,H,W,64]; weights DEVICE fp16 [2][1][7][2][64][8] (params.pack_pointwise_f16s: chunks of 32 input channels, 112 output rows);
-// shift DEVICE float[112]; out_a [N,H,W,ca], out_b [N,H,W,cout-ca].  Supported: cin = 64, cout = 112.
-extern "C" int pmn_pointwise_f16s(const float* in, const void* weights, const float* shift, float* out_a, float* out_b, int N, int H, int W,
-                                  int cin, int cout, int ca, void* stream) {
-    if (!in || !weights || !shift || !out_a || N < 1 || H < 1 || W < 1 || cout < 1 || ca < 1 || ca > cout) return PMN_ERR_ARG;
-    if (ca < cout && !out_b) return PMN_ERR_ARG;
-    F16sArgs a;
-    a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.relu = 0;
-    a.cout = cout; a.ca = ca; a.out_b = out_b;
-    if (cin == 64 && cout == 112) return launch_f16s<64, 112, 1, 1, 32, 48, 2, 3, 1, 2>(in, weights, shift, out_a, a, (hipStream_t)stream);
-    return PMN_ERR_SHAPE;
-}
-
 // =================================================================================================================================
 // Fused stem on the fp16 matrix cores: conv0 (3 -> 8, fp32 VALU, as pmn_stem) feeds conv1 (8 -> 8: 72 % of the stem's multiplies)
 // as split-operand MFMAs.  reference models/net.py:17-19, 51.

@@ -100,8 +100,6 @@ class FeatureNet(nn.Module):
             w8 = torch.from_numpy(np.ascontiguousarray(fold[8][0].T))[:, :, None, None]  # [112,64,1,1]: matrix-core form of level 1/8
             w, s = params.pack_conv_mfma(w8, bias=torch.from_numpy(fold[8][1]))
             pk["fpn8_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-            w, s = params.pack_pointwise_f16s(w8, torch.from_numpy(fold[8][1]))
-            pk["fpn8_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -139,9 +137,7 @@ class FeatureNet(nn.Module):
         if self.fold_fpn:
             # the FPN head is linear: its 1x1 convolutions are composed on the host (params.fold_fpn) and each level is one
             # bandwidth-bound kernel -- the 64-channel intermediates at 1/4 and 1/2 resolution never exist
-            if self.f16_split:  # 64 -> 112 channels: a GEMM, on the fp16 matrix cores (split operands)
-                f3, u8 = ops.pointwise_split_f16s(eighth, *pk["fpn8_f16s"], ca=64)
-            elif self.mfma_convs:  # ... on the fp32 matrix cores
+            if self.mfma_convs:  # 64 -> 112 channels: a GEMM, on the matrix cores
                 f3, u8 = ops.pointwise_split_mfma(eighth, *pk["fpn8_mfma"], cout=112, ca=64)
             else:
                 f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)

@@ -564,25 +564,6 @@ def offset_heads_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tenso
     return out_a, out_b
 
 
-def pointwise_split_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, ca: int):
-    """pmn_pointwise_f16s: out = x @ W + b on the fp16 matrix cores (split operands), output channels split between two channels-last
-    tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights / shift from params.pack_pointwise_f16s of the
-    [112,64,1,1] filter -> ([N,H,W,ca], [N,H,W,112-ca])."""
-    _dev(x, "x")
-    _dev(shift, "shift")
-    N, H, W, cin = x.shape
-    cout = shift.shape[0]
-    if not isinstance(weights, torch.Tensor) or not weights.is_cuda or weights.dtype != torch.float16 or not weights.is_contiguous() \
-            or tuple(weights.shape) != (cin // 32, 1, cout // 16, 2, 64, 8) or not 0 < ca < cout:
-        raise PmnError("pointwise_split_f16s: weights are not in pack_pointwise_f16s layout for this input")
-    out_a = torch.empty((N, H, W, ca), dtype=torch.float32, device=x.device)
-    out_b = torch.empty((N, H, W, cout - ca), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        check(_lib.lib().pmn_pointwise_f16s(x.data_ptr(), weights.data_ptr(), shift.data_ptr(), out_a.data_ptr(), out_b.data_ptr(), N, H,
-                                            W, cin, cout, ca, _stream(x)), "pmn_pointwise_f16s")
-    return out_a, out_b
-
-
 def fpn_level(x: torch.Tensor, u: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, ca: int):
     """pmn_fpn_level: one level of the folded FPN head, out = bilinear_x2(u) + b + x @ w (reference models/net.py:57-67 with
     the 1x1 convolutions composed, params.fold_fpn).  x [N,H,W,cin], u [N,H/2,W/2,cout] or None, w [cin,cout], b [cout]

@@ -298,16 +298,6 @@ def pack_offset_heads_f16s(weight: torch.Tensor, bias: torch.Tensor):
     return _pack_f16s(wp, 16), np.ascontiguousarray(shift.astype(np.float32))
 
 
-def pack_pointwise_f16s(weight: torch.Tensor, bias: torch.Tensor):
-    """1x1 filters [cout,cin,1,1] (cin a multiple of 32, cout a multiple of 16) + bias for pmn_pointwise_f16s: chunks of 32 input
-    channels (one k-step each) -> (float16 [cin/32, 1, cout/16, 2, 64, 8], float32 [cout])."""
-    w = _np64(weight)
-    cout, cin = w.shape[:2]
-    if w.shape[2:] != (1, 1) or cin % 32 or cout % 16:
-        raise ValueError("pack_pointwise_f16s: [cout,cin,1,1] with cin % 32 == 0 and cout % 16 == 0")
-    return _pack_f16s(w, 32), np.ascontiguousarray(_np64(bias).astype(np.float32))
-
-
 def pack_stem_conv1_f16s(weight: torch.Tensor, bn, eps: float = BN_EPS):
     """FeatureNet conv1 (8 -> 8, 3x3) for pmn_stem_f16s: the weights as the A operands (rows = output channels) of
     v_mfma_f32_16x16x32_f16 -> (float16 [3 k-steps][2 (hi|lo)][64 lanes][8], float32 shift [8]).  Lane l = 16 kb + row: row = output

@@ -466,22 +466,6 @@ def test_stem_kernels_against_torch(H, W):
         assert err < 1e-6, (name, err)
 
 
-def test_pointwise_f16_split_against_float64():
-    """pmn_pointwise_f16s (the 1/8-resolution FPN level as a split-operand fp16 MFMA GEMM, channels-last split outputs) vs float64."""
-    P = _gpu()
-    from patchmatchnet_amd import params as PP
-    gen = torch.Generator().manual_seed(12)
-    x = torch.randn(3, 19, 27, 64, generator=gen)
-    wt = 0.2 * torch.randn(112, 64, generator=gen)
-    bias = 0.1 * torch.randn(112, generator=gen)
-    ref = torch.einsum("nhwc,dc->nhwd", x.double(), wt.double()) + bias.double()
-    w, sh = PP.pack_pointwise_f16s(wt[:, :, None, None], bias)
-    a, b = P.ops.pointwise_split_f16s(x.to(DEV), torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV), ca=64)
-    got = torch.cat((a, b), 3).double().cpu()
-    assert tuple(a.shape) == (3, 19, 27, 64) and tuple(b.shape) == (3, 19, 27, 48)
-    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
-
-
 def test_fpn_level8_matrix_core_form_matches_valu_form():
     """The 1/8-resolution level of the folded FPN head: pmn_conv2d_mfma's split 1x1 form vs pmn_fpn_level (VALU) vs float64."""
     P = _gpu()
