@@ -239,3 +239,42 @@ def test_ply_writer_layout(tmp_path):
 def test_fusion_has_no_cpu_path():
     with pytest.raises(_lib.PmnError):
         fusion.fuse_views(torch.zeros(2, 2, 4, 4), {0: 0, 1: 1}, {}, {}, [], 1.0, 0.01, 1, 0.5)
+
+
+def test_rescaled_projection_reproduces_the_per_view_warp():
+    """ops.rescale_projection_rows (source maps of different sizes zero-padded into one buffer, CPU-checkable part): warping with
+    the PADDED size and the rescaled projection rows lands on the positions the reference's warp computes with the view's OWN
+    size (models/module.py:161-181: normalise by the reference map, un-normalise by the source map), to fp32 rounding."""
+    import ctypes
+    from oracle import oracle as O
+    from patchmatchnet_amd import ops
+    h, w, D = 24, 40, 6
+    sizes, padded = [(24, 40), (16, 32), (20, 36)], (24, 40)
+    intr, extr = synth.synthetic_cameras(4, h, w)
+    proj = synth.stage_projections(intr, extr, 1.0)
+    rels = []
+    for v, (hv, wv) in enumerate(sizes):
+        K = intr[0, v + 1].astype(np.float32).copy()
+        K[0] *= wv / w
+        K[1] *= hv / h
+        pr = extr[0, v + 1].astype(np.float32).copy()
+        pr[:3, :4] = K @ extr[0, v + 1, :3, :4].astype(np.float32)
+        rels.append(np.matmul(pr, np.linalg.inv(proj[0, 0])).astype(np.float32))
+    rel = torch.from_numpy(np.stack(rels))[None]  # [1,3,4,4]
+    scaled = ops.rescale_projection_rows(rel, sizes, padded).numpy()
+    assert ops.rescale_projection_rows(rel, [padded] * 3, padded) is rel  # nothing to do: same tensor
+    depth = np.ascontiguousarray(np.random.default_rng(0).uniform(450, 900, (D, h, w)).astype(np.float32))
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def positions(P, hs, ws):
+        rot, trans = np.ascontiguousarray(P[:3, :3]), np.ascontiguousarray(P[:3, 3])
+        ix, iy = np.empty((D, h, w), np.float32), np.empty((D, h, w), np.float32)
+        O.lib().pmo_warp_positions(rot.ctypes.data_as(f32p), trans.ctypes.data_as(f32p), depth.ctypes.data_as(f32p), D, h, w, hs, ws,
+                                   ix.ctypes.data_as(f32p), iy.ctypes.data_as(f32p))
+        return ix, iy
+
+    for v, (hv, wv) in enumerate(sizes):
+        want = positions(rel[0, v].numpy(), hv, wv)          # the reference's arithmetic at the view's own size
+        got = positions(scaled[0, v], *padded)               # what the kernel computes on the padded buffer
+        for a, b in zip(got, want):
+            assert np.abs(a - b).max() < 2e-3, (v, float(np.abs(a - b).max()))  # positions up to a few hundred px: fp32 rounding
