@@ -47,7 +47,8 @@ def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict
     maps [V,2,H,W] device float32 (slot_of[view id] -> slot) -- or, for a scan whose views differ in size, [V,F] flat slots with
     ``sizes[view id] = (h, w)`` (every view's depth then confidence packed at the start of its slot; reference eval.py:203-237
     reads every view's maps at their own size); cams[id] = {"intrinsics" [3,3], "extrinsics" [4,4]} (numpy
-    float32, intrinsics already scaled to the map size); images[ref id] = [H,W,3] float in [0,1] for the reference views.
+    float32, intrinsics already scaled to the map size); images[ref id] = [H,W,3] float in [0,1] for the reference views (or a
+    Future of it).
     Returns (vertices [M,3] float32, colors [M,3] uint8, masks {ref: (photo, geo, final) bool [H,W]}) in ``pairs`` order, points
     of a view in row-major pixel order -- the reference's order (eval.py:270-281)."""
     if not maps.is_cuda:
@@ -68,7 +69,10 @@ def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict
         verts.append(xyz[final].cpu().numpy())
         mk = m.cpu().numpy().astype(bool)
         masks[ref] = (mk[0], mk[1], mk[2])
-        img = np.asarray(images[ref])
+        img = images[ref]
+        if hasattr(img, "result"):  # a concurrent.futures.Future: eval.py decodes the reference images on a thread pool
+            img = img.result()
+        img = np.asarray(img)
         cols.append((img[mk[2]] * 255).astype(np.uint8))
     if not verts:
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), masks

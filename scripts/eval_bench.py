@@ -43,7 +43,8 @@ def run(tag, extra, scan_list=None):
     out = os.path.join(base, "out_" + tag)
     shutil.rmtree(out, ignore_errors=True)
     argv = ["--input_folder", data, "--output_folder", out, "--checkpoint_path", ckpt, "--scan_list",
-            scan_list or os.path.join(data, "list.txt"), "--num_views", "5", "--output_type", "depth", "--file_format", ".pfm"] + extra
+            scan_list or os.path.join(data, "list.txt"), "--num_views", "5", "--file_format", ".pfm"] + \
+        ([] if "--output_type" in extra else ["--output_type", "depth"]) + extra
     t = time.time()
     pm_eval.main(argv)
     dt = time.time() - t
@@ -61,6 +62,9 @@ results = []
 for threads in (4, 8, 16):
     results.append(run("decode_threads%d" % threads, ["--decode_threads", str(threads)]))
 results.append(run("default_flags", []))
+if "--both" in sys.argv:  # inference + consistency filtering + fusion (masks, fused.ply) of every scan
+    results.append(run("output_type_both", ["--output_type", "both", "--geo_mask_thres", "3"]))
+    results.append(run("output_type_both_1thread", ["--output_type", "both", "--geo_mask_thres", "3", "--decode_threads", "1"]))
 if "--all" in sys.argv:
     results.append(run("two_pass_workers8", ["--num_workers", "8", "--stream_views", "0"]))       # round 2's schedule (DataLoader processes)
     results.append(run("nocache_workers8", ["--num_workers", "8", "--feature_cache", "0"], scan_list=one))  # the reference's schedule
