@@ -579,15 +579,15 @@ def filter_depth(args, scan, produced, rank, world, device):
         slot_of.update({vid: base + i for i, vid in enumerate(extra)})
     a, b = pdist.block_range(len(pairs), rank, world)
     my_pairs = pairs[a:b]
-    # The host work around the fusion kernel -- decoding the reference images for the point colours (one JPEG per view) and
-    # encoding three mask PNGs per view -- is 60-80 ms per 1600x1200 view on one core, 20x the time of the view's whole inference;
-    # Pillow's codecs release the GIL, so both run on a thread pool beside the kernel launches (same files, same bytes).
+    # The host work around the fusion kernel -- decoding the reference image for the point colours, copying the masks / points off
+    # the device, numpy's boolean indexing, three mask PNGs -- is 50-60 ms per 1600x1200 view on one core, 20x the time of the view's
+    # whole inference; all of it releases the GIL, so it runs on a thread pool beside the kernel launches (same files, same bytes).
     t_fuse = time.time()
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "decode_threads", 8), 2), thread_name_prefix="pmn-fuse")
     images = {ref: pool.submit(lambda r=ref: read_image(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(r)),
                                                         args.image_max_dim)[0]) for ref, _ in my_pairs}
     vertices, colors, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None)
+                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool)
     os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
     writes = []
     for ref, (photo, geo, final) in masks.items():

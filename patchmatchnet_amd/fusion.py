@@ -41,7 +41,7 @@ def camera_block(K_ref: np.ndarray, E_ref: np.ndarray, srcs: Sequence[Tuple[np.n
 
 def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict], images: Dict[int, np.ndarray],
                pairs: List[Tuple[int, List[int]]], geo_pixel_thres: float, geo_depth_thres: float, geo_mask_thres: int,
-               photo_thres: float, sizes: Optional[Dict[int, Tuple[int, int]]] = None):
+               photo_thres: float, sizes: Optional[Dict[int, Tuple[int, int]]] = None, pool=None):
     """Fuses the reference views listed in ``pairs`` (this rank's share of a scan).
 
     maps [V,2,H,W] device float32 (slot_of[view id] -> slot) -- or, for a scan whose views differ in size, [V,F] flat slots with
@@ -53,27 +53,40 @@ def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict
     of a view in row-major pixel order -- the reference's order (eval.py:270-281)."""
     if not maps.is_cuda:
         raise PmnError("fusion runs on a ROCm GPU only (pmn_fuse_view); there is no CPU fallback")
-    verts, cols, masks = [], [], {}
     slot_sizes = None
     if sizes is not None:
         slot_sizes = [(1, 1)] * maps.shape[0]
         for vid, sl in slot_of.items():
             slot_sizes[sl] = tuple(sizes[vid])
+
+    def finish(ref, m, xyz):
+        """Host half of one reference view: masks and the kept points leave the device, colours are picked from the reference image
+        (eval.py:270-281).  Runs on ``pool`` when one is given: the copies and numpy's boolean indexing release the GIL, and at
+        50-60 ms per 1600x1200 view this half, not the kernel, is what a scan's fusion takes."""
+        with torch.cuda.device(m.device):  # a pool thread starts on device 0, whatever the rank's device is
+            final = m[2].bool()
+            v = xyz[final].cpu().numpy()
+            mk = m.cpu().numpy().astype(bool)
+        img = images[ref]
+        if hasattr(img, "result"):  # a concurrent.futures.Future: eval.py decodes the reference images on a thread pool
+            img = img.result()
+        img = np.asarray(img)
+        return v, (img[mk[2]] * 255).astype(np.uint8), (mk[0], mk[1], mk[2])
+
+    pending = []
     for ref, srcs in pairs:
         block = camera_block(cams[ref]["intrinsics"], cams[ref]["extrinsics"],
                              [(cams[s]["intrinsics"], cams[s]["extrinsics"]) for s in srcs])
         mats = torch.from_numpy(block).to(maps.device)
         m, xyz, _, _ = ops.fuse_view(maps, slot_of[ref], [slot_of[s] for s in srcs], mats, geo_pixel_thres, geo_depth_thres,
                                      geo_mask_thres, photo_thres, sizes=slot_sizes)
-        final = m[2].bool()
-        verts.append(xyz[final].cpu().numpy())
-        mk = m.cpu().numpy().astype(bool)
-        masks[ref] = (mk[0], mk[1], mk[2])
-        img = images[ref]
-        if hasattr(img, "result"):  # a concurrent.futures.Future: eval.py decodes the reference images on a thread pool
-            img = img.result()
-        img = np.asarray(img)
-        cols.append((img[mk[2]] * 255).astype(np.uint8))
+        pending.append((ref, pool.submit(finish, ref, m, xyz) if pool is not None else finish(ref, m, xyz)))
+    verts, cols, masks = [], [], {}
+    for ref, res in pending:
+        v, c, mk = res.result() if hasattr(res, "result") else res
+        verts.append(v)
+        cols.append(c)
+        masks[ref] = mk
     if not verts:
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), masks
     return np.concatenate(verts, 0), np.concatenate(cols, 0), masks
