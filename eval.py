@@ -30,7 +30,8 @@ import patchmatchnet_amd as P
 from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
 from patchmatchnet_amd.graph import GraphedForward
-from patchmatchnet_amd.data_io import image_shape, read_cam_file, read_image, read_map, read_pair_file, save_image, save_map
+from patchmatchnet_amd.data_io import (image_shape, read_cam_file, read_image, read_image_u8, read_map, read_pair_file, save_image,
+                                       save_map)
 from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
 
 
@@ -584,27 +585,34 @@ def filter_depth(args, scan, produced, rank, world, device):
     # whole inference; all of it releases the GIL, so it runs on a thread pool beside the kernel launches (same files, same bytes).
     t_fuse = time.time()
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "decode_threads", 8), 2), thread_name_prefix="pmn-fuse")
-    images = {ref: pool.submit(lambda r=ref: read_image(os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(r)),
-                                                        args.image_max_dim)[0]) for ref, _ in my_pairs}
-    vertices, colors, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool)
+    def ref_image(r):
+        path = os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(r))
+        u8 = read_image_u8(path, args.image_max_dim)  # the decoded bytes when no down-scaling applies: they are the point colours
+        return u8 if u8 is not None else read_image(path, args.image_max_dim)[0]
+
+    images = {ref: pool.submit(ref_image, ref) for ref, _ in my_pairs}
     os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
-    writes = []
+
+    def write_masks(ref, masks):  # on the pool thread that finished the view, while later views are still being fused
+        for kind, m in zip(("photo", "geo", "final"), masks):
+            save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_{}.png".format(ref, kind)), m)
+
+    records, _, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
+                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool,
+                                                on_view=write_masks, as_records=True)  # returns when every view is fused and its masks are on disk
     for ref, (photo, geo, final) in masks.items():
-        for kind, m in (("photo", photo), ("geo", geo), ("final", final)):
-            writes.append(pool.submit(save_image, os.path.join(args.output_folder, scan, "mask/{:0>8}_{}.png".format(ref, kind)), m))
+        # count / size = the float64 mean of a bool array the reference prints (eval.py:262-265), without the float64 pass
         print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
-            os.path.join(args.input_folder, scan), ref, geo.mean(), photo.mean(), final.mean()))
-    for f in writes:
-        f.result()  # re-raises a writer's exception; every mask is on disk before the scan is reported
+            os.path.join(args.input_folder, scan), ref, np.count_nonzero(geo) / geo.size, np.count_nonzero(photo) / photo.size,
+            np.count_nonzero(final) / final.size))
     pool.shutdown(wait=True)
     ply = os.path.join(args.output_folder, scan, "fused.ply")
     if world == 1:
-        fusion.write_ply(ply, vertices, colors)
+        fusion.write_ply_records(ply, records)
     else:
         # per-rank raw vertex records next to the target; rank 0 writes the header for the total and appends the parts in rank
         # (= pair-file) order: the same bytes a single-rank run writes
-        fusion.ply_records(vertices, colors).tofile(ply + ".part{}".format(rank))
+        fusion.write_ply_records(ply + ".part{}".format(rank), records, header=False)
         torch.distributed.barrier()
         if rank == 0:
             parts = [ply + ".part{}".format(r) for r in range(world)]

@@ -41,16 +41,21 @@ def camera_block(K_ref: np.ndarray, E_ref: np.ndarray, srcs: Sequence[Tuple[np.n
 
 def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict], images: Dict[int, np.ndarray],
                pairs: List[Tuple[int, List[int]]], geo_pixel_thres: float, geo_depth_thres: float, geo_mask_thres: int,
-               photo_thres: float, sizes: Optional[Dict[int, Tuple[int, int]]] = None, pool=None):
+               photo_thres: float, sizes: Optional[Dict[int, Tuple[int, int]]] = None, pool=None, on_view=None,
+               as_records: bool = False):
     """Fuses the reference views listed in ``pairs`` (this rank's share of a scan).
 
     maps [V,2,H,W] device float32 (slot_of[view id] -> slot) -- or, for a scan whose views differ in size, [V,F] flat slots with
     ``sizes[view id] = (h, w)`` (every view's depth then confidence packed at the start of its slot; reference eval.py:203-237
     reads every view's maps at their own size); cams[id] = {"intrinsics" [3,3], "extrinsics" [4,4]} (numpy
-    float32, intrinsics already scaled to the map size); images[ref id] = [H,W,3] float in [0,1] for the reference views (or a
-    Future of it).
+    float32, intrinsics already scaled to the map size); images[ref id] = the reference view's image, [H,W,3] float in [0,1] as read_image returns it or the
+    decoded uint8 bytes (which are the colours), or a Future of either.
     Returns (vertices [M,3] float32, colors [M,3] uint8, masks {ref: (photo, geo, final) bool [H,W]}) in ``pairs`` order, points
-    of a view in row-major pixel order -- the reference's order (eval.py:270-281)."""
+    of a view in row-major pixel order -- the reference's order (eval.py:270-281).  ``on_view(ref, (photo, geo, final))`` is called
+    as soon as a view's masks are on the host, on the thread that finished the view (eval.py writes the mask PNGs there, while
+    later views are still being fused).  ``as_records``: returns ([PLY vertex records of every view], None, masks) instead -- the
+    records are packed on the finishing threads and ``write_ply_records`` streams them to the file, so a scan's points (1.4 GB for
+    49 fully consistent 1600x1200 views) are never concatenated or copied again on the launch thread."""
     if not maps.is_cuda:
         raise PmnError("fusion runs on a ROCm GPU only (pmn_fuse_view); there is no CPU fallback")
     slot_sizes = None
@@ -66,12 +71,23 @@ def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict
         with torch.cuda.device(m.device):  # a pool thread starts on device 0, whatever the rank's device is
             final = m[2].bool()
             v = xyz[final].cpu().numpy()
-            mk = m.cpu().numpy().astype(bool)
+            mk = m.cpu().numpy()
+        mk = mk.view(bool) if mk.dtype == np.uint8 else mk.astype(bool)  # the kernel writes 0 / 1 bytes
         img = images[ref]
         if hasattr(img, "result"):  # a concurrent.futures.Future: eval.py decodes the reference images on a thread pool
             img = img.result()
         img = np.asarray(img)
-        return v, (img[mk[2]] * 255).astype(np.uint8), (mk[0], mk[1], mk[2])
+        if img.dtype == np.uint8:
+            # the decoded bytes ARE the colours: the reference's float32 k / 255.0 (datasets/data_io.py:45) then (color * 255)
+            # .astype(uint8) (eval.py:275) returns k for every byte value (tests/test_io_and_dist.py) -- no float image needed
+            c = img[mk[2]]
+        else:
+            c = (img[mk[2]] * 255).astype(np.uint8)
+        if on_view is not None:
+            on_view(ref, (mk[0], mk[1], mk[2]))
+        if as_records:
+            return ply_records(v, c), None, (mk[0], mk[1], mk[2])
+        return v, c, (mk[0], mk[1], mk[2])
 
     pending = []
     for ref, srcs in pairs:
@@ -87,6 +103,8 @@ def fuse_views(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict
         verts.append(v)
         cols.append(c)
         masks[ref] = mk
+    if as_records:
+        return verts, None, masks
     if not verts:
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), masks
     return np.concatenate(verts, 0), np.concatenate(cols, 0), masks
@@ -112,12 +130,17 @@ def fuse_scan(views: Dict[int, Dict], pairs: List[Tuple[int, List[int]]], geo_pi
                       geo_mask_thres, photo_thres, sizes=sizes)
 
 
+PLY_VERTEX = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+
+
 def ply_records(vertices: np.ndarray, colors: np.ndarray) -> np.ndarray:
-    rec = np.empty(len(vertices), dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"),
-                                         ("blue", "u1")])
-    if len(vertices):
-        rec["x"], rec["y"], rec["z"] = vertices[:, 0], vertices[:, 1], vertices[:, 2]
-        rec["red"], rec["green"], rec["blue"] = colors[:, 0], colors[:, 1], colors[:, 2]
+    """The 15-byte vertex records of the PLY body (two strided byte copies: positions, colours)."""
+    n = len(vertices)
+    rec = np.empty(n, dtype=PLY_VERTEX)
+    if n:
+        raw = rec.view(np.uint8).reshape(n, 15)
+        raw[:, :12] = np.ascontiguousarray(vertices, "<f4").view(np.uint8).reshape(n, 12)
+        raw[:, 12:] = np.asarray(colors, np.uint8)
     return rec
 
 
@@ -134,3 +157,16 @@ def write_ply(filename: str, vertices: np.ndarray, colors: np.ndarray) -> None:
     with open(filename, "wb") as f:
         f.write(ply_header(len(rec)))
         rec.tofile(f)
+
+
+def write_ply_records(filename: str, chunks, header: bool = True) -> int:
+    """The same file as ``write_ply`` from per-view record arrays (``fuse_views(as_records=True)``), streamed chunk by chunk;
+    ``header=False`` writes the bare records (eval.py's per-rank parts).  Returns the number of vertices."""
+    total = sum(len(c) for c in chunks)
+    os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+    with open(filename, "wb") as f:
+        if header:
+            f.write(ply_header(total))
+        for c in chunks:
+            c.tofile(f)
+    return total

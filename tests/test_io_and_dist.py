@@ -234,6 +234,12 @@ def test_ply_writer_layout(tmp_path):
     np.testing.assert_array_equal(rec["x"], v[:, 0])
     np.testing.assert_array_equal(rec["blue"], c[:, 2])
     assert fusion.ply_header(11) + fusion.ply_records(v, c).tobytes() == raw
+    # the streamed form eval.py uses (per-view record chunks, incl. an empty one) writes the same bytes; the bare form is the body
+    chunks = [fusion.ply_records(v[:4], c[:4]), fusion.ply_records(v[:0], c[:0]), fusion.ply_records(v[4:], c[4:])]
+    assert fusion.write_ply_records(str(tmp_path / "s.ply"), chunks) == 11
+    assert open(str(tmp_path / "s.ply"), "rb").read() == raw
+    fusion.write_ply_records(str(tmp_path / "s.part0"), chunks, header=False)
+    assert open(str(tmp_path / "s.part0"), "rb").read() == body
 
 
 def test_fusion_has_no_cpu_path():
@@ -278,3 +284,12 @@ def test_rescaled_projection_reproduces_the_per_view_warp():
         got = positions(scaled[0, v], *padded)               # what the kernel computes on the padded buffer
         for a, b in zip(got, want):
             assert np.abs(a - b).max() < 2e-3, (v, float(np.abs(a - b).max()))  # positions up to a few hundred px: fp32 rounding
+
+
+def test_point_colours_are_the_decoded_bytes():
+    """fusion takes point colours straight from the decoded BYTES when the image is not down-scaled; the reference goes byte ->
+    float32 / 255.0 (datasets/data_io.py:45) -> (color * 255).astype(uint8) (eval.py:275).  That round trip is the identity for
+    every byte value, so both give the same colours."""
+    k = np.arange(256, dtype=np.uint8)
+    img = np.array(k, dtype=np.float32) / 255.0
+    np.testing.assert_array_equal((img * 255).astype(np.uint8), k)
