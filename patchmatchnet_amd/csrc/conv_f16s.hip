@@ -290,37 +290,45 @@ extern "C" int pmn_offset_heads_f16s(const float* in, const void* weights, const
 // Fused stem on the fp16 matrix cores: conv0 (3 -> 8, fp32 VALU, as pmn_stem) feeds conv1 (8 -> 8: 72 % of the stem's multiplies)
 // as split-operand MFMAs.  reference models/net.py:17-19, 51.
 //
-// Workgroup = TS x TS output pixels (TS = 16).  (1) planar (TS+4)^2 x 3 input patch -> LDS; (2) every thread evaluates conv0 + BatchNorm +
-// ReLU for its pixel of the (TS+2)^2 halo patch (zero outside the image: conv1 pads conv0's OUTPUT map), splits the 8 channels into hi / lo
-// fp16 and writes two planes [18][18][8 halves] (16 B per pixel: a ds_read_b128 lane group {pixels i} x {tap q, tap q + 1} touches 16
-// distinct slots or the same address -- brute-forced); (3) conv1 with the ROLES SWAPPED: the MFMA's A operand (rows) = the 8 output
-// channels (rows 8..15 zero), the B operand (columns) = 16 consecutive pixels of one output row, k = (tap, channel): 9 blocks of 8
-// channels = 3 k-steps (3 padding blocks).  D then holds, in lane (pixel i, kb), output channels 4 kb .. 4 kb + 3 of pixel i for kb = 0, 1:
-// one float4 store per lane, 512 contiguous bytes per 16-pixel row of the channels-last output.  Wave w owns output rows 4 w .. 4 w + 3.
+// Workgroup = 16 x 16 output pixels.  (1) input patch -> LDS as 3 x 20 rows of 24 floats, x = ox0 - 4 .. ox0 + 19: with W % 4 == 0
+// (VEC4; every size the network itself produces) a row is six ALIGNED float4 loads, each entirely inside or outside the image, and
+// the index arithmetic is shifts (the scalar staging it replaces spent 165 VALU instructions per thread on / and %); (2) every thread
+// evaluates conv0 + BatchNorm + ReLU for its pixel of the 18 x 18 halo patch (zero outside the image: conv1 pads conv0's OUTPUT map),
+// splits the 8 channels into hi / lo fp16 and writes two planes [18][18][8 halves] (16 B per pixel: a ds_read_b128 lane group {pixels
+// i} x {tap q, tap q + 1} touches 16 distinct slots or the same address -- brute-forced); (3) conv1 with the ROLES SWAPPED: the MFMA's
+// A operand (rows) = the 8 output channels (rows 8..15 zero), the B operand (columns) = 16 consecutive pixels of one output row,
+// k = (tap, channel): 9 blocks of 8 channels = 3 k-steps (3 padding blocks).  D then holds, in lane (pixel i, kb), output channels
+// 4 kb .. 4 kb + 3 of pixel i for kb = 0, 1: one float4 store per lane, 512 contiguous bytes per 16-pixel row of the channels-last
+// output.  Wave w owns output rows 4 w .. 4 w + 3.
+//
+// What it waits for (scripts/experiments/README.md, phase ablation): the phases' costs add up -- it is bound by instruction issue, not
+// by HBM (84 MB per 1600 x 1200 view = 10.5 us) -- so the kernel is written for few instructions: 404 -> 235 static VALU instructions
+// against the first version (vector staging, halo pixels outside the image skip conv0, split and epilogue on 2- / 4-vectors, one
+// output pointer per lane), 44 -> 38 us per view with bit-identical results.  Tried and measured equal: a 14 x 14 tile (halo patch =
+// one pass of 256 threads), alternating the second conv0 pass between wave pairs, 8 instead of 6 workgroups per CU.
 // =================================================================================================================================
-template <int TS>
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
                                                           const float* __restrict__ s0, const f16x8* __restrict__ w1A,
                                                           const float* __restrict__ s1, float* __restrict__ out, const int N,
                                                           const int H, const int W) {
-    // TS = 16 is what runs.  TS = 14 makes conv0's halo patch 16 x 16 = ONE pixel per thread (with 16 x 16 outputs it is 18 x 18 = 324
-    // pixels: a second pass in which 68 of 256 threads work); the MFMA tile stays 16 pixels wide and the spare columns / rows compute on
-    // whatever the planes hold and are not stored (an MFMA column only sees its own B column).  Measured on one box: 294.7 vs 295.6 us
-    // per six views -- the second pass is not what the kernel waits for -- so the tile that divides 1600 x 1200 stays.
-    constexpr int TW = TS, TH = TS, IW = TS + 4, IWP = IW + 1, MW = TS + 2, MRP = 18, MROWS = 18, NTHR = 256;
-    static_assert(TS == 14 || TS == 16, "tile of 14 or 16 output pixels");
-    __shared__ float xin[3 * IW * IWP];
-    __shared__ float4 mid4[2 * MROWS * MRP];  // two planes of 18 x 18 pixel slots x 8 halves (16 B); MW x MW of them are written
+    constexpr int TS = 16, IW = TS + 4, XS = 24, MW = TS + 2, MRP = 18, MROWS = 18, NTHR = 256;
+    __shared__ float4 xin4[3 * IW * (XS / 4)];
+    __shared__ float4 mid4[2 * MROWS * MRP];  // two planes of 18 x 18 pixel slots x 8 halves (16 B)
+    float* xin = reinterpret_cast<float*>(xin4);
     _Float16* midh = reinterpret_cast<_Float16*>(mid4);
     _Float16* midl = midh + MROWS * MRP * 8;
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
     const cfloat* cs0 = (const cfloat*)s0;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kb = lane >> 4;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
     const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
     const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
-    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TW;
+    const int oy0 = (tr / tiles_x) * TS, ox0 = (tr % tiles_x) * TS;
 
     // conv1's weights (A operands of the three k-steps, hi | lo): six 1 KB loads per wave, in flight across the staging below
     f16x8 wa[3][2];
@@ -329,23 +337,38 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         wa[ks][0] = w1A[(ks * 2 + 0) * 64 + lane];
         wa[ks][1] = w1A[(ks * 2 + 1) * 64 + lane];
     }
-    {   // (1) input patch, every load of the thread in flight before the first LDS write
-        constexpr int NL = (3 * IW * IW + NTHR - 1) / NTHR;
-        float v[NL];
+    // (1) input patch, every load of the thread in flight before the first LDS write.  Row R of 60 = (channel, patch row).
+    if constexpr (VEC4) {
+        float4 v[2];
+        const int j = tid & 7, gx = ox0 - 4 + 4 * j;  // float4 j of the row (6 used)
 #pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const int idx = tid + u * NTHR;
-            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
-            const int gy = oy0 - 2 + r, gx = ox0 - 2 + q;
+        for (int u = 0; u < 2; ++u) {
+            const int R = (tid >> 3) + 32 * u;
+            const int c = (R >= IW) + (R >= 2 * IW), r = R - IW * c, gy = oy0 - 2 + r;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < 6 && R < 3 * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v[u] = *reinterpret_cast<const float4*>(img + (((size_t)n * 3 + c) * H + gy) * W + gx);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int R = (tid >> 3) + 32 * u;
+            if (j < 6 && R < 3 * IW) xin4[R * (XS / 4) + j] = v[u];
+        }
+    } else {  // any width: one float per thread, 8 rows of 32 columns (24 used) per pass
+        float v[8];
+        const int q = tid & 31, gx = ox0 - 4 + q;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int R = (tid >> 5) + 8 * u;
+            const int c = (R >= IW) + (R >= 2 * IW), r = R - IW * c, gy = oy0 - 2 + r;
             v[u] = 0.0f;
-            if (idx < 3 * IW * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            if (q < XS && R < 3 * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
                 v[u] = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
         }
 #pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const int idx = tid + u * NTHR;
-            const int c = idx / (IW * IW), r = (idx / IW) % IW, q = idx % IW;
-            if (idx < 3 * IW * IW) xin[(c * IW + r) * IWP + q] = v[u];
+        for (int u = 0; u < 8; ++u) {
+            const int R = (tid >> 5) + 8 * u;
+            if (q < XS && R < 3 * IW) xin[R * XS + q] = v[u];
         }
     }
     __syncthreads();
@@ -353,29 +376,35 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
     for (int m = tid; m < MW * MW; m += NTHR) {
         const int r = m / MW, q = m - r * MW;
         const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
-        float acc[8];
+        f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            float acc[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+            for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+            const float* xp = xin + r * XS + q + 2;  // input x = gx - 1 + kx = (ox0 - 4) + q + 2 + kx
 #pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-            const cfloat* wq = cw0 + __builtin_amdgcn_readfirstlane(ky * 72);
+            for (int ky = 0; ky < 3; ++ky) {
+                const cfloat* wq = cw0 + __builtin_amdgcn_readfirstlane(ky * 72);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float v = xin[(ci * IW + r + ky) * IWP + q + kx];
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float v = xp[(ci * IW + ky) * XS + kx];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wq[(kx * 3 + ci) * 8 + c], acc[c]);
-                }
-        }
-        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        f16x8 hi, lo;
+                        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wq[(kx * 3 + ci) * 8 + c], acc[c]);
+                    }
+            }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float x = inside ? fmaxf(acc[c] + cs0[c], 0.0f) : 0.0f;
-            const _Float16 h = (_Float16)x;
-            hi[c] = h;
-            lo[c] = (_Float16)((x - (float)h) * PMN_F16S_LO_SCALE);
+            for (int c = 0; c < 8; c += 2) {
+                const f32x2_t x = {fmaxf(acc[c] + cs0[c], 0.0f), fmaxf(acc[c + 1] + cs0[c + 1], 0.0f)};
+                const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+                const f32x2_t d = (x - __builtin_convertvector(h, f32x2_t)) * PMN_F16S_LO_SCALE;
+                const f16x2_t l = __builtin_convertvector(d, f16x2_t);
+                hi[c] = h[0];
+                hi[c + 1] = h[1];
+                lo[c] = l[0];
+                lo[c + 1] = l[1];
+            }
         }
         *reinterpret_cast<f16x8*>(midh + (r * MRP + q) * 8) = hi;
         *reinterpret_cast<f16x8*>(midl + (r * MRP + q) * 8) = lo;
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         int q = 4 * ks + kb;
         q = q < 8 ? q : 8;  // padding blocks 9..11 (zero weights) read tap 8
         const int dy = q / 3, dx = q - dy * 3;
-        // (rows up to 4*3 + 3 + 2 = 17 and columns up to 15 + 2 = 17: inside the 18 x 18 slots also when MW = 16)
+        // (rows up to 4*3 + 3 + 2 = 17 and columns up to 15 + 2 = 17: inside the 18 x 18 slots)
         const _Float16* pb = midh + ((wave * 4 + dy) * MRP + li + dx) * 8;
         f16x8 bh[4], blo[4];
 #pragma unroll
@@ -409,19 +438,17 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][1], bh[t], accL[t], 0, 0, 0);
     }
     // D rows 4 kb + r = output channels: lanes with kb < 2 hold channels [4 kb, 4 kb + 4) of pixel (ox0 + li, oy0 + 4 wave + t)
-    if (kb < 2 && li < TW) {
-        const float4 sh = *reinterpret_cast<const float4*>(s1 + 4 * kb);
-        const int ox = ox0 + li;
+    const int ox = ox0 + li, oyw = oy0 + wave * 4;
+    if (kb < 2 && ox < W) {
+        const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(s1 + 4 * kb);
+        float* po = out + (((size_t)n * H + oyw) * W + ox) * 8 + 4 * kb;
+        const size_t rs = (size_t)W * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int oy = oy0 + wave * 4 + t;
-            if (wave * 4 + t < TH && oy < H && ox < W) {
-                float4 v;
-                v.x = fmaxf(accM[t][0] + accL[t][0] * (1.0f / PMN_F16S_LO_SCALE) + sh.x, 0.0f);
-                v.y = fmaxf(accM[t][1] + accL[t][1] * (1.0f / PMN_F16S_LO_SCALE) + sh.y, 0.0f);
-                v.z = fmaxf(accM[t][2] + accL[t][2] * (1.0f / PMN_F16S_LO_SCALE) + sh.z, 0.0f);
-                v.w = fmaxf(accM[t][3] + accL[t][3] * (1.0f / PMN_F16S_LO_SCALE) + sh.w, 0.0f);
-                *reinterpret_cast<float4*>(out + (((size_t)n * H + oy) * W + ox) * 8 + 4 * kb) = v;
+            if (oyw + t < H) {
+                f32x4_t v = accM[t] + accL[t] * (1.0f / PMN_F16S_LO_SCALE) + sh;
+                v = __builtin_elementwise_max(v, f32x4_t{0.f, 0.f, 0.f, 0.f});
+                *reinterpret_cast<f32x4_t*>(po + t * rs) = v;
             }
         }
     }
@@ -434,8 +461,13 @@ extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0,
     if (!img || !w0 || !s0 || !w1a || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
     constexpr int TS = 16;
     const int blocks = N * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
-    hipLaunchKernelGGL(stem_f16s_kernel<TS>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
-                       reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
+    // aligned float4 staging needs 16-byte aligned image rows: W % 4 == 0 and a 16-byte aligned base
+    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0)
+        hipLaunchKernelGGL(stem_f16s_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
+    else
+        hipLaunchKernelGGL(stem_f16s_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

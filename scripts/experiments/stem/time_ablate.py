@@ -24,6 +24,15 @@ for N in (1, 6):
     img = torch.rand(N, 3, H, W, generator=g).to(dev)
     out = torch.empty(N, H, W, 8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    for var in [m_ for m_ in (64, 128) if m_ in masks]:  # variant 2 against the product kernel's text, incl. an image whose tiles are cut by the border
+        for (h2, w2) in ((H, W), (1187, 1596), (50, 68)):
+            im2 = torch.rand(N, 3, h2, w2, generator=g).to(dev)
+            a, b = torch.full((N, h2, w2, 8), -1.0, device=dev), torch.full((N, h2, w2, 8), -2.0, device=dev)
+            lib.stem_abl(im2.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(), a.data_ptr(), N, h2, w2, 0, st)
+            lib.stem_abl(im2.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(), b.data_ptr(), N, h2, w2, var, st)
+            torch.cuda.synchronize()
+            print("N=%d %dx%d variant %d vs product text: max |diff| %.3e, equal bits: %s" % (
+                N, w2, h2, var, float((a - b).abs().max()), bool(torch.equal(a, b))), flush=True)
     for abl in masks:
         for _ in range(5):
             lib.stem_abl(img.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(), out.data_ptr(), N, H, W, abl, st)

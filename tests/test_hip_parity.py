@@ -438,7 +438,7 @@ def test_conv_f16_split_against_torch(k, stride, cin, cout, H, W):
     assert err < 1e-6, err
 
 
-@pytest.mark.parametrize("H,W", [(37, 51), (16, 16), (150, 200)])
+@pytest.mark.parametrize("H,W", [(37, 51), (16, 16), (150, 200), (50, 68)])
 def test_stem_kernels_against_torch(H, W):
     """pmn_stem (conv0 + conv1 on the fp32 VALU) and pmn_stem_f16s (conv1 on the fp16 matrix cores, split operands) vs
     conv + BatchNorm + ReLU twice in float64 (reference models/net.py:17-19, 51); partial tiles, image borders (conv1 pads conv0's
@@ -464,6 +464,11 @@ def test_stem_kernels_against_torch(H, W):
         assert tuple(g.shape) == (2, H, W, 8)
         err = float((g.double().cpu() - ref).abs().max() / ref.abs().max())
         assert err < 1e-6, (name, err)
+    # pmn_stem_f16s stages the image with aligned float4 loads when W % 4 == 0 and the base is 16-byte aligned, one float at a time
+    # otherwise: the same image at a base that is off by one float must give the same bits
+    shifted = torch.empty(x.numel() + 1, device=DEV)[1:].view(x.shape).copy_(x.to(DEV))
+    assert shifted.data_ptr() % 16 != 0 and shifted.is_contiguous()
+    assert torch.equal(P.ops.stem_f16s(shifted, *p0, *p1h), got_h)
 
 
 def test_fpn_level8_matrix_core_form_matches_valu_form():
