@@ -28,6 +28,8 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 struct F16sArgs {
     int N, H, W, Ho, Wo, relu;
@@ -39,7 +41,7 @@ struct F16sArgs {
 
 // DIL = dilation (padding DIL * (KS / 2)); OUTMODE 0: out [N,Ho,Wo,COUT] channels-last; 1: planar, split: out [N,ca,Ho,Wo] | out_b
 // [N,cout-ca,Ho,Wo] (the offset heads of a PatchMatch stage: propa_conv rows, then eval_conv rows); 2: channels-last, split.
-template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0>
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0, bool SWAP = (OUTMODE == 0)>
 __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __restrict__ in, const f16x8* __restrict__ wB,
                                                              const float* __restrict__ shift, float* __restrict__ out,
                                                              const F16sArgs a) {
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
     constexpr int PAD = DIL * (KS / 2);
     constexpr int PLANE = PH * PW * CCP;  // halves per plane
     constexpr int NTHR = 256;
+    static_assert(!SWAP || OUTMODE == 0, "swapped operand roles (see the epilogue) serve the channels-last output");
     static_assert(CCP % 8 == 0 && CC % 8 == 0 && CIN % CC == 0, "16-byte aligned channel blocks");
     extern __shared__ float4 f16s_lds4[];
     _Float16* Phi = reinterpret_cast<_Float16*>(f16s_lds4);
@@ -76,37 +79,50 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
         bq[0][nt][1] = bl[(size_t)((0 * NT + nt) * 2 + 1) * 64];
     }
 
+    // staging position of the thread's first unit (see the patch block): pixel tid / QP of the patch, channel quad tid % QP
+    const int q4x4 = 4 * (tid % (CC / 4)), pix_first = tid / (CC / 4);
+    const int py_first = pix_first / PW, px_first = pix_first - py_first * PW, lds_first = pix_first * CCP + q4x4;
+
 #pragma unroll 1
     for (int ch = 0; ch < CHUNKS; ++ch) {
         if (ch) __syncthreads();  // every wave is done with the previous chunk's patch
-        {   // ---- patch: PH x PW pixels x CC/4 channel quads -> split -> two fp16 planes; SB loads of a thread in flight per batch
+        {   // ---- patch: PH x PW pixels x CC/4 channel quads -> split -> two fp16 planes; SB loads of a thread in flight per batch.
+            // Written for few instructions (these layers issue about as many VALU cycles in this block as MFMA cycles in the k loop):
+            // unit idx = tid + k NTHR is pixel pix0 + k DPIX, quad q4 -- the pixel's (row, column) advances by a constant step with
+            // one wrap instead of a division per load, the LDS slot is a compile-time offset from the thread's first one, the global
+            // address is a uniform base + a 32-bit offset (host: H W CIN < 2^30), the split runs on 2-vectors.
             constexpr int QP = CC / 4, TOT = PH * PW * QP, NL = (TOT + NTHR - 1) / NTHR, SB = 6;
+            constexpr int DPIX = NTHR / QP, DY = DPIX / PW, DX = DPIX - DY * PW;
+            static_assert(NTHR % QP == 0, "a step of NTHR units is a whole number of pixels");
+            const float* src = in + (size_t)n * a.H * a.W * CIN + ch * CC;  // uniform
+            int py = py_first, px = px_first;
 #pragma unroll
             for (int k0 = 0; k0 < NL; k0 += SB) {
                 float4 v[SB];
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
-                    const int idx = tid + (k0 + k) * NTHR, pix = idx / QP, q4 = idx - pix * QP;
-                    const int py = pix / PW, px = pix - py * PW;
                     const int gy = iy0 + py, gx = ix0 + px;
                     v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k0 + k < NL && idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                        v[k] = *reinterpret_cast<const float4*>(in + (((size_t)n * a.H + gy) * a.W + gx) * CIN + ch * CC + 4 * q4);
+                    if (k0 + k < NL && tid < TOT - (k0 + k) * NTHR && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                        v[k] = *reinterpret_cast<const float4*>(src + ((unsigned)(gy * a.W + gx) * CIN + q4x4));
+                    px += DX;
+                    py += DY;
+                    if (px >= PW) {
+                        px -= PW;
+                        ++py;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < SB; ++k) {
-                    const int idx = tid + (k0 + k) * NTHR, pix = idx / QP, q4 = idx - pix * QP;
-                    if (k0 + k < NL && idx < TOT) {
-                        const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                        f16x4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const _Float16 h = (_Float16)x[e];  // round to nearest even
-                            hi[e] = h;
-                            lo[e] = (_Float16)((x[e] - (float)h) * PMN_F16S_LO_SCALE);  // x - hi is exact in fp32
-                        }
-                        *reinterpret_cast<f16x4*>(Phi + pix * CCP + 4 * q4) = hi;
-                        *reinterpret_cast<f16x4*>(Plo + pix * CCP + 4 * q4) = lo;
+                    if (k0 + k < NL && tid < TOT - (k0 + k) * NTHR) {
+                        const f32x2_t x01 = {v[k].x, v[k].y}, x23 = {v[k].z, v[k].w};
+                        const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);  // RNE
+                        // x - hi is exact in fp32
+                        const f16x2_t l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+                        const f16x2_t l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+                        const f16x4 hi = {h01[0], h01[1], h23[0], h23[1]}, lo = {l01[0], l01[1], l23[0], l23[1]};
+                        *reinterpret_cast<f16x4*>(Phi + lds_first + (k0 + k) * DPIX * CCP) = hi;
+                        *reinterpret_cast<f16x4*>(Plo + lds_first + (k0 + k) * DPIX * CCP) = lo;
                     }
                 }
             }
@@ -147,17 +163,20 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    accM[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][0], accM[t][nt], 0, 0, 0);
+                    accM[t][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][nt][0], ah[t], accM[t][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][0], accM[t][nt], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    accL[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][1], accL[t][nt], 0, 0, 0);
+                    accL[t][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][nt][1], ah[t], accL[t][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bq[cur][nt][1], accL[t][nt], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    accL[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bq[cur][nt][0], accL[t][nt], 0, 0, 0);
+                    accL[t][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][nt][0], al[t], accL[t][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bq[cur][nt][0], accL[t][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (KSTEPS & 1) {  // an odd number of k-steps leaves the prefetched operands in slot 1: the next chunk starts from slot 0
@@ -169,7 +188,33 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
         }
     }
 
-    // ---- epilogue: main + low / 2048 + shift (folded BatchNorm / bias), ReLU; lane = output channel 16 nt + li, rows 4 kb + r = pixels
+    // ---- epilogue: main + low / 2048 + shift (folded BatchNorm / bias), ReLU.
+    if constexpr (SWAP) {
+        // channels-last output: the MFMAs ran with the operand roles swapped (rows = output channels, columns = pixels), so lane
+        // (li, kb) holds channels 16 nt + 4 kb .. + 3 of pixel ox0 + li -- one 16-byte store per tile, 64 contiguous bytes per pixel
+        // and N-tile (with the roles as staged it is four 4-byte stores per tile and their address arithmetic)
+        const int ox = ox0 + li, oyw = oy0 + wave * MT;
+        if (ox < a.Wo) {
+            float* po = out + (((size_t)n * a.Ho + oyw) * a.Wo + ox) * COUT + 4 * kb;
+            const size_t rs = (size_t)a.Wo * COUT;
+            f32x4_t sh[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sh[nt] = *reinterpret_cast<const f32x4_t*>(shift + 16 * nt + 4 * kb);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                if (oyw + t < a.Ho) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4_t v = accM[t][nt] + accL[t][nt] * (1.0f / PMN_F16S_LO_SCALE) + sh[nt];
+                        if (a.relu) v = __builtin_elementwise_max(v, f32x4_t{0.f, 0.f, 0.f, 0.f});
+                        *reinterpret_cast<f32x4_t*>(po + t * rs + 16 * nt) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // planar / split outputs (the offset heads): lane = output channel 16 nt + li, rows 4 kb + r = pixels
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int c = nt * 16 + li;
@@ -217,11 +262,12 @@ __global__ __launch_bounds__(256, WPS) void conv_f16s_kernel(const float* __rest
     }
 }
 
-template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0>
+template <int CIN, int COUT, int KS, int S, int CC, int CCP, int MT, int WPS, int DIL = 1, int OUTMODE = 0, bool SWAP = (OUTMODE == 0)>
 static int launch_f16s(const float* in, const void* w, const float* shift, float* out, F16sArgs a, hipStream_t st) {
     constexpr int TH = 4 * MT, PH = (TH - 1) * S + (KS - 1) * DIL + 1, PW = 15 * S + (KS - 1) * DIL + 1;
     const size_t lds = (size_t)2 * PH * PW * CCP * sizeof(_Float16);
-    auto kern = conv_f16s_kernel<CIN, COUT, KS, S, CC, CCP, MT, WPS, DIL, OUTMODE>;
+    auto kern = conv_f16s_kernel<CIN, COUT, KS, S, CC, CCP, MT, WPS, DIL, OUTMODE, SWAP>;
+    if ((size_t)a.H * a.W * CIN >= ((size_t)1 << 30)) return PMN_ERR_SHAPE;  // the kernel addresses one image with a 32-bit offset
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f16x8*>(w), shift, out, a);
@@ -246,12 +292,15 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
     // persistent variant that prefetches the next (tile, chunk) behind the MFMAs with the B operands staged in LDS
     // (scripts/experiments/conv_f16s_persistent_prefetch.hip.txt: correct, 5-10 % slower) -- these layers are bound by operand delivery
     // (8 KB of B operands per 384 MFMA cycles and wave = 85 B/clk/CU against the L1's 64), not by the latency of the patch loads.
+    // Operand roles (last template argument; scripts/experiments/f16s_ab/, same box, bit-identical either way): swapped (one 16-byte
+    // store per tile) wins for one and four N-tiles -- 16->16 96 -> 83 us, 64->64 58 -> 53, 8->16 138 -> 131, 32->64 80 -> 75 per six
+    // views -- and loses for two (32->32 55.6 as staged vs 61.2 swapped, 16->32 88.5 vs 91.1), which therefore keep the staged roles.
     //                                                            CIN COUT KS S  CC CCP MT WPS
     if (k == 3 && stride == 1 && cin == 16 && cout == 16) return launch_f16s<16, 16, 3, 1, 16, 16, 4, 4>(in, weights, shift, out, a, st);
-    if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 16, 16, 2, 4>(in, weights, shift, out, a, st);
+    if (k == 3 && stride == 1 && cin == 32 && cout == 32) return launch_f16s<32, 32, 3, 1, 16, 16, 2, 4, 1, 0, false>(in, weights, shift, out, a, st);
     if (k == 3 && stride == 1 && cin == 64 && cout == 64) return launch_f16s<64, 64, 3, 1, 16, 16, 2, 3>(in, weights, shift, out, a, st);
     if (k == 5 && stride == 2 && cin == 8 && cout == 16) return launch_f16s<8, 16, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
-    if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 8, 8, 2, 4>(in, weights, shift, out, a, st);
+    if (k == 5 && stride == 2 && cin == 16 && cout == 32) return launch_f16s<16, 32, 5, 2, 8, 8, 2, 4, 1, 0, false>(in, weights, shift, out, a, st);
     if (k == 5 && stride == 2 && cin == 32 && cout == 64) return launch_f16s<32, 64, 5, 2, 16, 24, 2, 2>(in, weights, shift, out, a, st);
     return PMN_ERR_SHAPE;
 }
@@ -307,9 +356,6 @@ extern "C" int pmn_offset_heads_f16s(const float* in, const void* weights, const
 // output pointer per lane), 44 -> 38 us per view with bit-identical results.  Tried and measured equal: a 14 x 14 tile (halo patch =
 // one pass of 256 threads), alternating the second conv0 pass between wave pairs, 8 instead of 6 workgroups per CU.
 // =================================================================================================================================
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-
 template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
                                                           const float* __restrict__ s0, const f16x8* __restrict__ w1A,
