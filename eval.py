@@ -508,18 +508,25 @@ def save_depth(args, rank, world, device, on_scan_done=None):
             main_stream.wait_stream(st)
         del pyramids, images
 
-    with torch.no_grad():
-        # scan by scan in the scan list's order on EVERY rank: also a rank that owns no reference view of a scan (fewer views than
-        # ranks) reaches scan_finished, whose fusion step holds the per-scan collective
-        for scan in dataset.scans:
-            for light, indices in by_scan.get(scan, []):
-                run_group(scan, light, indices)
-            scan_finished(scan)
-    for st in streams:
-        main_stream.wait_stream(st)
-    if view_stream is not None:
-        view_stream.close()
-    writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
+    finished = False
+    try:
+        with torch.no_grad():
+            # scan by scan in the scan list's order on EVERY rank: also a rank that owns no reference view of a scan (fewer views
+            # than ranks) reaches scan_finished, whose fusion step holds the per-scan collective
+            for scan in dataset.scans:
+                for light, indices in by_scan.get(scan, []):
+                    run_group(scan, light, indices)
+                scan_finished(scan)
+        for st in streams:
+            main_stream.wait_stream(st)
+        finished = True
+    finally:  # an exception above must not leave decode / writer threads working through their queues behind the traceback
+        if view_stream is not None:
+            view_stream.close()
+        if finished:
+            writer.close()  # every map is on disk before anybody (fusion of another run, the caller) may read it
+        else:
+            writer.pool.shutdown(wait=True, cancel_futures=True)
     torch.cuda.synchronize(device)
     t_end = time.time()
     print("depth stage: {} samples in {:.3f} s after a {:.3f} s model load -> {:.1f} depth-maps/s on this rank (decode, upload, "
@@ -591,21 +598,24 @@ def filter_depth(args, scan, produced, rank, world, device):
         return u8 if u8 is not None else read_image(path, args.image_max_dim)[0]
 
     images = {ref: pool.submit(ref_image, ref) for ref, _ in my_pairs}
-    os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
+    try:
+        os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
 
-    def write_masks(ref, masks):  # on the pool thread that finished the view, while later views are still being fused
-        for kind, m in zip(("photo", "geo", "final"), masks):
-            save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_{}.png".format(ref, kind)), m)
+        def write_masks(ref, masks):  # on the pool thread that finished the view, while later views are still being fused
+            for kind, m in zip(("photo", "geo", "final"), masks):
+                save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_{}.png".format(ref, kind)), m)
 
-    records, _, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                                args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool,
-                                                on_view=write_masks, as_records=True)  # returns when every view is fused and its masks are on disk
-    for ref, (photo, geo, final) in masks.items():
-        # count / size = the float64 mean of a bool array the reference prints (eval.py:262-265), without the float64 pass
-        print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
-            os.path.join(args.input_folder, scan), ref, np.count_nonzero(geo) / geo.size, np.count_nonzero(photo) / photo.size,
-            np.count_nonzero(final) / final.size))
-    pool.shutdown(wait=True)
+        # returns when every view is fused and its masks are on disk
+        records, _, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
+                                              args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool,
+                                              on_view=write_masks, as_records=True)
+        for ref, (photo, geo, final) in masks.items():
+            # count / size = the float64 mean of a bool array the reference prints (eval.py:262-265), without the float64 pass
+            print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
+                os.path.join(args.input_folder, scan), ref, np.count_nonzero(geo) / geo.size, np.count_nonzero(photo) / photo.size,
+                np.count_nonzero(final) / final.size))
+    finally:
+        pool.shutdown(wait=True, cancel_futures=True)
     ply = os.path.join(args.output_folder, scan, "fused.ply")
     if world == 1:
         fusion.write_ply_records(ply, records)
