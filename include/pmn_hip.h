@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 15
+#define PMN_ABI_VERSION 16
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -215,6 +215,14 @@ int pmn_refine_front(const float *img, const float *t2, const float *w0, const f
                      float *x16, int B, int H, int W, void *stream);
 int pmn_refine_tail(const float *x16, const float *w3, const float *s3, const float *wr, const float *dnorm,
                     const float *depth_min, const float *depth_max, float *out, int B, int H, int W, void *stream);
+
+/* The same half in ONE launch (what Refinement.forward_hip runs): pmn_refine_front's and pmn_refine_tail's arguments without the x16
+ * buffer between them, and conv3 on the fp16 matrix cores with split operands -- w3a DEVICE float16 [5][2][64][8] / s3 [8] from
+ * patchmatchnet_amd/params.py pack_refine_conv3_f16s (conv3's weights as MFMA A operands, hi | lo, BatchNorm folded).  The x16
+ * intermediate (123 MB per 1600x1200 depth map) stays in LDS.  H, W even. */
+int pmn_refine_fused(const float *img, const float *t2, const float *w0, const float *s0, const float *wd, const float *sd,
+                     const void *w3a, const float *s3, const float *wr, const float *dnorm, const float *depth_min,
+                     const float *depth_max, float *out, int B, int H, int W, void *stream);
 
 /* Relative projections of every (stage, batch element, source view): rel = P_src @ inverse(P_ref) with
  * P = [[K_s @ E[:3,:4]], [E[3,:]]] and K_s = K with rows 0,1 scaled by scale0 * 2^stage (reference models/net.py:225-231,

@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -46,6 +46,7 @@ SIGNATURES = {
     "pmn_offset_heads_f16s": [_fp] * 5 + [_i] * 7 + [_s],
     "pmn_refine_front": [_fp] * 7 + [_i] * 3 + [_s],
     "pmn_refine_tail": [_fp] * 8 + [_i] * 3 + [_s],
+    "pmn_refine_fused": [_fp] * 13 + [_i] * 3 + [_s],
     "pmn_conv2d_mfma": [_fp] * 5 + [_i] * 12 + [_s],
     "pmn_deconv3x3s2": [_fp] * 4 + [_i] * 6 + [_s],
     "pmn_stage_projections": [_fp, _fp, _i, _i, _i, _f, _fp, _s],

@@ -165,7 +165,7 @@ class FeatureNet(nn.Module):
 
 class Refinement(nn.Module):
     """Depth-residual refinement at full resolution (reference models/net.py:73-122).  ``forward`` = PyTorch-ROCm (parity
-    reference), ``forward_hip`` = pmn_conv2d at half resolution + the fused pmn_refine_front / pmn_refine_tail (default)."""
+    reference), ``forward_hip`` = pmn_conv2d at half resolution + pmn_refine_fused (default; ``one_kernel = False``: pmn_refine_front / pmn_refine_tail)."""
 
     def __init__(self) -> None:
         super().__init__()
@@ -177,6 +177,7 @@ class Refinement(nn.Module):
         self.conv3 = ConvBnReLU(in_channels=16, out_channels=8)
         self.res = nn.Conv2d(8, 1, kernel_size=3, padding=1, bias=False)
         self.fused_tail = True  # forward_hip: pmn_refine_front + pmn_refine_tail (False = one launch per layer)
+        self.one_kernel = True  # ... and those two as ONE launch, conv3 on the fp16 matrix cores (pmn_refine_fused); needs fused_tail
 
     def _packed(self):
         srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
@@ -198,6 +199,8 @@ class Refinement(nn.Module):
             pk["res"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             pk["tail"] = tuple(torch.from_numpy(a).to(dev) for a in params.pack_refine_tail(
                 self.conv3.conv.weight, bn_of(self.conv3.bn), self.res.weight, eps=self.conv3.bn.eps))
+            w, s = params.pack_refine_conv3_f16s(self.conv3.conv.weight, bn_of(self.conv3.bn), eps=self.conv3.bn.eps)
+            pk["conv3_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -212,7 +215,10 @@ class Refinement(nn.Module):
         t = ops.conv2d(d, *pk["conv1"], 8, 3, 1, 1, relu=True, in_nchw=True)                             # [B,H/2,W/2,8]
         t = ops.conv2d(t, *pk["conv2"], 8, 3, 1, 1, relu=True)
         if self.fused_tail and img.shape[2] % 2 == 0 and img.shape[3] % 2 == 0:
-            # full-resolution half in two launches: (deconv || conv0) -> x16, then conv3 -> res -> residual + de-normalisation
+            if self.one_kernel:  # the full-resolution half in one launch: x16 never leaves LDS
+                return ops.refine_fused(img.contiguous(), t, *pk["conv0"], *pk["deconv"], *pk["conv3_f16s"], pk["tail"][2], d,
+                                        depth_min.float().contiguous(), depth_max.float().contiguous())
+            # ... in two launches: (deconv || conv0) -> x16, then conv3 -> res -> residual + de-normalisation
             x16 = ops.refine_front(img.contiguous(), t, *pk["conv0"], *pk["deconv"])
             return ops.refine_tail(x16, *pk["tail"], d, depth_min.float().contiguous(), depth_max.float().contiguous())
         img_feat = ops.conv2d(img.contiguous(), *pk["conv0"], 8, 3, 1, 1, relu=True, in_nchw=True)      # [B,H,W,8]

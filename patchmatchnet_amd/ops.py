@@ -622,6 +622,31 @@ def refine_tail(x16: torch.Tensor, w3: torch.Tensor, s3: torch.Tensor, wr: torch
     return out
 
 
+def refine_fused(img: torch.Tensor, t2: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, wd: torch.Tensor, sd: torch.Tensor,
+                 w3a: torch.Tensor, s3: torch.Tensor, wr: torch.Tensor, dnorm: torch.Tensor, depth_min: torch.Tensor,
+                 depth_max: torch.Tensor) -> torch.Tensor:
+    """pmn_refine_fused: refine_front + refine_tail in one launch, conv3 on the fp16 matrix cores with split operands (reference
+    models/net.py:110-122); img [B,3,H,W], t2 [B,H/2,W/2,8], w3a = params.pack_refine_conv3_f16s (float16 [5,2,64,8]), dnorm
+    [B,1,H/2,W/2], depth_min / depth_max [B] -> [B,1,H,W]."""
+    for n_, t_ in (("img", img), ("t2", t2), ("w0", w0), ("s0", s0), ("wd", wd), ("sd", sd), ("s3", s3), ("wr", wr), ("dnorm", dnorm),
+                   ("depth_min", depth_min), ("depth_max", depth_max)):
+        _dev(t_, n_)
+    if not isinstance(w3a, torch.Tensor) or not w3a.is_cuda or w3a.dtype != torch.float16 or tuple(w3a.shape) != (5, 2, 64, 8) \
+            or not w3a.is_contiguous():
+        raise PmnError("refine_fused: w3a must be the float16 [5,2,64,8] tensor of params.pack_refine_conv3_f16s on a ROCm GPU")
+    B, c, H, W = img.shape
+    if c != 3 or H % 2 or W % 2 or tuple(t2.shape) != (B, H // 2, W // 2, 8) or tuple(dnorm.shape) != (B, 1, H // 2, W // 2) or \
+            tuple(w0.shape) != (3, 3, 3, 8) or tuple(wd.shape) != (3, 3, 8, 8) or tuple(wr.shape) != (3, 3, 8) or s3.numel() != 8 or \
+            depth_min.numel() != B or depth_max.numel() != B:
+        raise PmnError("refine_fused: inconsistent shapes")
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        check(_lib.lib().pmn_refine_fused(img.data_ptr(), t2.data_ptr(), w0.data_ptr(), s0.data_ptr(), wd.data_ptr(), sd.data_ptr(),
+                                          w3a.data_ptr(), s3.data_ptr(), wr.data_ptr(), dnorm.data_ptr(), depth_min.data_ptr(),
+                                          depth_max.data_ptr(), out.data_ptr(), B, H, W, _stream(img)), "pmn_refine_fused")
+    return out
+
+
 def deconv3x3s2(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """pmn_deconv3x3s2: ConvTranspose2d(k3,s2,p1,op1) + folded BN + ReLU; x [N,Hi,Wi,8] -> [N,2Hi,2Wi,8]."""
     _dev(x, "x")

@@ -318,6 +318,27 @@ def pack_stem_conv1_f16s(weight: torch.Tensor, bn, eps: float = BN_EPS):
     return np.ascontiguousarray(np.stack((hi, lo), axis=1)), np.ascontiguousarray(shift.astype(np.float32))
 
 
+def pack_refine_conv3_f16s(weight: torch.Tensor, bn, eps: float = BN_EPS):
+    """Refinement.conv3 (16 -> 8, 3x3 + BatchNorm) for pmn_refine_fused: the weights as the A operands (rows = output channels) of
+    v_mfma_f32_16x16x32_f16 -> (float16 [5 k-steps][2 (hi|lo)][64 lanes][8], float32 shift [8]).  Lane l = 16 kb + row (rows 8..15
+    zero); k-block q = 4 ks + kb = 2 tap + cb (tap = dy * 3 + dx, cb = half of the 16 input channels; blocks 18, 19 zero); the 8 values =
+    input channels 8 cb .. 8 cb + 7; BatchNorm scale folded in float64, every weight split with ``split_f16``."""
+    w = _np64(weight)
+    if w.shape != (8, 16, 3, 3):
+        raise ValueError("pack_refine_conv3_f16s: conv3 is 16 -> 8, 3x3")
+    g, b, m, v = (_np64(t) for t in bn)
+    sc = g / np.sqrt(v + eps)
+    w = w * sc[:, None, None, None]
+    shift = b - m * sc
+    full = np.zeros((5, 4, 16, 8), np.float64)  # [ks][kb][row][e]
+    for q in range(18):
+        tap, cb = q >> 1, q & 1
+        dy, dx = divmod(tap, 3)
+        full[q // 4, q % 4, :8, :] = w[:, 8 * cb:8 * cb + 8, dy, dx]
+    hi, lo = split_f16(full.reshape(5, 64, 8))
+    return np.ascontiguousarray(np.stack((hi, lo), axis=1)), np.ascontiguousarray(shift.astype(np.float32))
+
+
 def pack_deconv(weight: torch.Tensor, bn=None, eps: float = BN_EPS):
     """ConvTranspose2d weight [cin,cout,K,K] (+ BatchNorm2d tensors) -> (float32 [K,K,cin,cout], float32 [cout]) for
     pmn_deconv3x3s2; BatchNorm folded in float64."""

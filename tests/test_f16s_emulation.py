@@ -187,3 +187,40 @@ def test_emulated_offset_heads(cin, dil, n_p, n_e):
     want = F.conv2d(x.double(), w.double(), b.double(), 1, dil, dil).permute(0, 2, 3, 1).numpy()
     err = np.abs(got - want).max() / np.abs(want).max()
     assert err < 5e-7, err
+
+
+def test_refine_conv3_packing_against_float64():
+    """params.pack_refine_conv3_f16s (pmn_refine_fused's conv3: A operands = output channels, k-block q = 4 ks + kb = 2 tap + channel
+    half) summed exactly as the kernel sums it -- hi*hi + (hi*lo + lo*hi) / 2048 over the five k-steps, the two padding blocks read
+    block 17 against zero weights -- vs conv3 + BatchNorm + ReLU in float64 (reference models/net.py:90, 117)."""
+    gen = torch.Generator().manual_seed(3)
+    w3 = 0.15 * torch.randn(8, 16, 3, 3, generator=gen)
+    bn = (0.5 + torch.rand(8, generator=gen), 0.1 * torch.randn(8, generator=gen), 0.1 * torch.randn(8, generator=gen),
+          0.5 + torch.rand(8, generator=gen))
+    x16 = torch.relu(torch.randn(1, 16, 9, 11, generator=gen)) * 3.0
+    c3 = torch.nn.functional.conv2d(x16.double(), w3.double(), None, 1, 1)
+    c3 = torch.relu(torch.nn.functional.batch_norm(c3, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0,
+                                                   params.BN_EPS))[0].numpy()
+    w3a, s3 = params.pack_refine_conv3_f16s(w3, bn)
+    assert w3a.shape == (5, 2, 64, 8) and w3a.dtype == np.float16 and s3.shape == (8,)
+    A = w3a.astype(np.float64)
+    assert (A[:, :, [16 * kb + r for kb in range(4) for r in range(8, 16)]] == 0).all()  # MFMA rows 8..15 are padding
+    assert (A[4, :, 32:] == 0).all()  # k-blocks 18, 19
+    xh, xl = params.split_f16(x16[0].numpy())
+    xh, xl = (np.pad(a.astype(np.float64), ((0, 0), (1, 1), (1, 1))) for a in (xh, xl))
+    worst = 0.0
+    for y in range(9):
+        for x in (0, 4, 10):
+            main, low = np.zeros(8), np.zeros(8)
+            for ks in range(5):
+                for kb in range(4):
+                    q = min(4 * ks + kb, 17)
+                    tap, cb = q >> 1, q & 1
+                    dy, dx = divmod(tap, 3)
+                    bh, bl = xh[8 * cb:8 * cb + 8, y + dy, x + dx], xl[8 * cb:8 * cb + 8, y + dy, x + dx]
+                    ah, al = A[ks, 0, 16 * kb:16 * kb + 8], A[ks, 1, 16 * kb:16 * kb + 8]
+                    main += ah @ bh
+                    low += ah @ bl + al @ bh
+            got = np.maximum(main + low / 2048.0 + s3.astype(np.float64), 0.0)
+            worst = max(worst, float(np.abs(got - c3[:, y, x]).max() / np.abs(c3).max()))
+    assert worst < 1e-6, worst

@@ -531,15 +531,18 @@ def test_stage_projections_kernel():
                 assert np.abs(rel[s, b, v - 1] - want).max() / np.abs(want).max() < 2e-6
 
 
-@pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("B,H,W", [(1, 96, 128), (2, 50, 70)])
-def test_refinement_hip_matches_miopen(fused, B, H, W):
-    """Refinement through pmn_refine_front / pmn_refine_tail (fused) or pmn_conv2d / pmn_deconv3x3s2 (layer by layer) vs the
-    same module on PyTorch-ROCm (MIOpen); ragged tiles and batch > 1 included."""
+@pytest.mark.parametrize("mode", ["one_kernel", "two_kernels", "layers"])
+@pytest.mark.parametrize("B,H,W", [(1, 96, 128), (2, 50, 70), (1, 38, 52)])
+def test_refinement_hip_matches_miopen(mode, B, H, W):
+    """Refinement through pmn_refine_fused (one launch, conv3 on the fp16 matrix cores with split operands: the default),
+    pmn_refine_front / pmn_refine_tail (two launches) or pmn_conv2d / pmn_deconv3x3s2 (layer by layer) vs the same module on
+    PyTorch-ROCm (MIOpen); ragged tiles, W % 4 != 0 (the scalar staging path) and batch > 1 included.  The one-launch form must
+    agree with the two-launch form far inside the tolerance: they differ by conv3's split-fp16 rounding only."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
-    model.upsample_net.fused_tail = fused
+    model.upsample_net.fused_tail = mode != "layers"
+    model.upsample_net.one_kernel = mode == "one_kernel"
     gen = torch.Generator().manual_seed(5 + H)
     img = torch.rand(B, 3, H, W, generator=gen).to(DEV)
     d0 = (425.0 + 510.0 * torch.rand(B, 1, H // 2, W // 2, generator=gen)).to(DEV)
@@ -547,6 +550,10 @@ def test_refinement_hip_matches_miopen(fused, B, H, W):
     with torch.no_grad():
         ref = model.upsample_net(img, d0, dmin, dmax)
         got = model.upsample_net.forward_hip(img, d0, dmin, dmax)
+        if mode == "one_kernel":
+            model.upsample_net.one_kernel = False
+            two = model.upsample_net.forward_hip(img, d0, dmin, dmax)
+            assert float(((got - two).abs() / two.abs()).max()) < 2e-6
     assert got.shape == ref.shape
     assert float(((got - ref).abs() / ref.abs()).max()) < 1e-5
 
