@@ -187,6 +187,9 @@ __device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
 }
 
 
+// corr_mfma.hip: correlate-then-interpolate on the fp32 matrix cores.  Returns PMN_ERR_SHAPE when the shape is not covered.
+int pmn_launch_corr_mfma(GatherArgs& a, int C, int G, bool pixelwise, hipStream_t stream);
+
 #ifdef PMN_EXPERIMENTAL  // `make EXPERIMENTAL=1`: the three LDS-window research families (csrc/experimental/, DESIGN.md lessons 17, 23)
 // gather_win.hip: windowed implementation of MODE_VIEWS / MODE_PIXELWISE.  Returns PMN_ERR_SHAPE when the shape is not covered
 // (the caller then uses the streaming kernel of gather_corr.hip).

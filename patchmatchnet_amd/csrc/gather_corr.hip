@@ -672,6 +672,14 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
         if (rc != PMN_ERR_SHAPE) return rc;
     }
 #endif
+    {   // round 4: the matrix-core formulation (corr_mfma.hip) for the shapes it covers; PMN_CORR_IMPL=stream keeps the streaming
+        // kernel (same-box A/B during development)
+        const char* impl = getenv("PMN_CORR_IMPL");
+        if (!(impl && strcmp(impl, "stream") == 0) && (size_t)hs * ws * C * 4 < (1ull << 32)) {
+            const int rc = pmn_launch_corr_mfma(a, C, G, view_weights_in == nullptr, (hipStream_t)stream);
+            if (rc != PMN_ERR_SHAPE) return rc;
+        }
+    }
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }
