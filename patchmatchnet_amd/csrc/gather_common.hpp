@@ -187,9 +187,6 @@ __device__ __forceinline__ float mul_add_unfused(float acc, float a, float b) {
 }
 
 
-// corr_mfma.hip: correlate-then-interpolate on the fp32 matrix cores.  Returns PMN_ERR_SHAPE when the shape is not covered.
-int pmn_launch_corr_mfma(GatherArgs& a, int C, int G, bool pixelwise, hipStream_t stream);
-
 #ifdef PMN_EXPERIMENTAL  // `make EXPERIMENTAL=1`: the three LDS-window research families (csrc/experimental/, DESIGN.md lessons 17, 23)
 // gather_win.hip: windowed implementation of MODE_VIEWS / MODE_PIXELWISE.  Returns PMN_ERR_SHAPE when the shape is not covered
 // (the caller then uses the streaming kernel of gather_corr.hip).
@@ -201,4 +198,6 @@ int pmn_lane_set_tuning(int key, int value);
 int pmn_launch_gather_tile(GatherArgs& a, int C, int G, hipStream_t stream);
 int pmn_tile_set_tuning(int key, int value);
 int pmn_gather_flags();  // pmn_set_tuning key 1
+// corr_mfma.hip: correlate-then-interpolate on the fp32 matrix cores (round 4).  Returns PMN_ERR_SHAPE when the shape is not covered.
+int pmn_launch_corr_mfma(GatherArgs& a, int C, int G, bool pixelwise, hipStream_t stream);
 #endif

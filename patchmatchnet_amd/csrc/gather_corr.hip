@@ -662,6 +662,10 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     // The product library has none of this: every launch is the streaming kernel below.
     const int flags = pmn_gather_flags();
     const bool pixelwise = view_weights_in == nullptr;
+    if (flags & 64) {  // round 4: correlate-then-interpolate on the fp32 matrix cores (experimental/corr_mfma.hip)
+        const int rc = pmn_launch_corr_mfma(a, C, G, pixelwise, (hipStream_t)stream);
+        if (rc != PMN_ERR_SHAPE) return rc;
+    }
     if ((flags & 32) && !pixelwise) {
         const int rc = pmn_launch_gather_tile(a, C, G, (hipStream_t)stream);
         if (rc != PMN_ERR_SHAPE) return rc;
@@ -672,14 +676,6 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
         if (rc != PMN_ERR_SHAPE) return rc;
     }
 #endif
-    {   // round 4: the matrix-core formulation (corr_mfma.hip) for the shapes it covers; PMN_CORR_IMPL=stream keeps the streaming
-        // kernel (same-box A/B during development)
-        const char* impl = getenv("PMN_CORR_IMPL");
-        if (!(impl && strcmp(impl, "stream") == 0) && (size_t)hs * ws * C * 4 < (1ull << 32)) {
-            const int rc = pmn_launch_corr_mfma(a, C, G, view_weights_in == nullptr, (hipStream_t)stream);
-            if (rc != PMN_ERR_SHAPE) return rc;
-        }
-    }
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }

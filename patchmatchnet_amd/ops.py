@@ -47,7 +47,7 @@ def disable_kernel_timing():
 TUNE_WINDOW_BYTES, TUNE_FLAGS, TUNE_WINDOW_BYTES_PIXELWISE, TUNE_ABLATE = 0, 1, 2, 3
 TUNE_LANE_WINDOW_BYTES, TUNE_LANE_ABLATE, TUNE_LANE_WAVES_PER_SIMD = 4, 5, 6
 TUNE_TILE_WINDOW_BYTES = 10
-FLAG_WINDOWED, FLAG_NO_ROTATION, FLAG_STREAM_PIXELWISE, FLAG_STREAM_VIEWS, FLAG_WIN_V1, FLAG_TILE = 1, 2, 4, 8, 16, 32
+FLAG_WINDOWED, FLAG_NO_ROTATION, FLAG_STREAM_PIXELWISE, FLAG_STREAM_VIEWS, FLAG_WIN_V1, FLAG_TILE, FLAG_MFMA = 1, 2, 4, 8, 16, 32, 64
 DEFAULT_FLAGS = 0  # the library default: streaming kernels for every launch (the fastest measured, profiles/README.md)
 
 

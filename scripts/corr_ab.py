@@ -3,10 +3,11 @@
 
 Runs one PatchmatchNet.forward on bench.py's sample (photo-consistent scene, reference checkpoint), records the arguments of
 every pmn_warp_correlate call (five per depth map at the default iterations), then replays each call under
-PMN_CORR_IMPL=stream (gather_corr.hip) and =mfma (corr_mfma.hip): HIP-event time per launch (median / min of --reps), the
-algorithmic bytes of SURVEY.md 8(d), and the difference between the two outputs.
+the streaming kernel (gather_corr.hip) and the research build's matrix-core formulation (experimental/corr_mfma.hip, pmn_set_tuning
+key 1 bit 6): HIP-event time per launch (median / min of --reps), the algorithmic bytes of SURVEY.md 8(d), and the difference
+between the two outputs.  Needs the research build: `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1` and PMN_EXPERIMENTAL=1.
 
-    python scripts/corr_ab.py [--width 1600 --height 1200 --views 5] [--reps 30] [--impls stream mfma]
+    PMN_EXPERIMENTAL=1 python scripts/corr_ab.py [--width 1600 --height 1200 --views 5] [--reps 30] [--impls stream mfma]
 """
 import argparse
 import json
@@ -109,8 +110,11 @@ def main():
         calls.append((a, kw))
         return real(*a, **kw)
 
+    def select(impl):
+        ops.set_tuning(ops.TUNE_FLAGS, ops.FLAG_MFMA if impl == "mfma" else 0)
+
     ops.warp_correlate = recorder
-    os.environ["PMN_CORR_IMPL"] = "stream"
+    select("stream")
     torch.manual_seed(0)
     with torch.no_grad():
         model(s["images"], s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
@@ -136,7 +140,7 @@ def main():
         kw2 = dict(kw)
         kw2["want_similarity"] = True
         for impl in args.impls:
-            os.environ["PMN_CORR_IMPL"] = impl
+            select(impl)
             med, mn = timed(lambda: real(*a, **kw), args.reps)
             cost, vwo, argmax, sim = real(*a, **kw2)
             torch.cuda.synchronize()

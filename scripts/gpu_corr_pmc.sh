@@ -1,6 +1,7 @@
 #!/bin/bash
 # gpurun payload: window statistics + SQ counters of the matrix-core pmn_warp_correlate on a real forward's arguments
 export TMPDIR=/tmp
+export PMN_EXPERIMENTAL=1  # the matrix-core formulation lives in the research build
 OUT=$GRAFT_REPO_ROOT/gpurun_out/corr_pmc
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 python scripts/corr_ab.py --windows 2>&1 | grep -v amdgpu.ids | tee $OUT/windows.txt

@@ -1,19 +1,20 @@
-"""pmn_warp_correlate has two formulations in the product library since round 4:
+"""OPT-IN (research build): runs only with PMN_EXPERIMENTAL=1 and `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`
+(libpmn_hip_experimental.so); skipped in the product configuration, whose library has the streaming kernel alone.
 
-  * correlate-then-interpolate on the fp32 matrix cores (csrc/corr_mfma.hip, the default for the cascade's shapes), and
-  * the streaming kernel (csrc/gather_corr.hip: blend C channels per tap, then correlate; every other shape).
+Round 4's second formulation of pmn_warp_correlate: correlate-then-interpolate on the fp32 matrix cores
+(csrc/experimental/corr_mfma.hip, pmn_set_tuning key 1 bit 6) next to the product's streaming kernel (csrc/gather_corr.hip:
+blend C channels per tap, then correlate).  Measured slower on every launch of the cascade (profiles/r04_corr_mfma.md), kept
+as a tested record.
 
 Both use the same tap positions and corner weights (reference models/module.py:130-181); they differ in the order of the
 channel sum and the 4-tap blend (reference models/patchmatch.py:198-203), i.e. by fp32 re-association.  The streaming kernel is
-the one pinned against the oracle / the reference's golden tensors in tests/test_hip_parity.py (which now run the matrix-core
-form where it covers the shape); this file ties the two to each other on data that exercises every path of the new kernel:
+the one pinned against the oracle / the reference's golden tensors in tests/test_hip_parity.py; this file ties the two to each
+other on data that exercises every path of the matrix-core kernel (and re-runs the golden kernel tests with it selected):
 window fits the wave's LDS buffer / is walked in pieces (unsorted hypotheses), ragged tiles, tiles straddling image rows,
 behind-camera and out-of-range hypotheses, batch > 1, half-resolution view weights, source maps of another size.
 Tolerances (absolute, on O(1) quantities): aggregated similarity 2e-5, cost 2e-4 (MLP of it), view weights 1e-5; arg-max
 equal wherever the two largest PixelwiseNet responses of the streaming kernel are not within 1e-5 of each other.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -28,6 +29,9 @@ CG = {64: 8, 32: 8, 16: 4}  # channels -> groups (reference models/net.py:153-15
 def _gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
+    from patchmatchnet_amd import _lib
+    if not _lib.experimental():
+        pytest.skip("research kernel families: opt in with PMN_EXPERIMENTAL=1 (+ make EXPERIMENTAL=1)")
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops
     P.lib()
@@ -86,18 +90,14 @@ def _case(C, D, h, w, N, B, hyp, seed, vw_shift=0, pixelwise=False, hs=None, ws=
 
 def _run(ops, impl, case, C, pixelwise, sim_mlp, pix_mlp, vw_shift=0):
     ref, src, rel, depth, vw = case
-    old = os.environ.get("PMN_CORR_IMPL")
-    os.environ["PMN_CORR_IMPL"] = impl
+    ops.set_tuning(ops.TUNE_FLAGS, ops.FLAG_MFMA if impl == "mfma" else 0)
     try:
         cost, vwo, argmax, sim = ops.warp_correlate(ref, src, rel, depth, vw, vw_shift, sim_mlp,
                                                     pix_mlp if pixelwise else None, CG[C], want_similarity=True,
                                                     want_argmax=pixelwise)
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            os.environ.pop("PMN_CORR_IMPL", None)
-        else:
-            os.environ["PMN_CORR_IMPL"] = old
+        ops.set_tuning(ops.TUNE_FLAGS, ops.DEFAULT_FLAGS)
     out = dict(cost=cost.clone(), sim=sim.clone())
     if pixelwise:
         out.update(vw=vwo.clone(), argmax=argmax.clone())
@@ -136,6 +136,10 @@ VIEWS = [
     (16, 8, 26, 40, 3, 1, "outside"),        # most taps outside the source map (dead items, border taps)
     (32, 16, 21, 30, 2, 1, "outside"),
     (16, 8, 16, 16, 1, 1, "sorted_band"),    # smallest map the ABI accepts in practice, one view
+    (32, 12, 19, 33, 2, 1, "sorted_band"),   # D % 8 != 0 (variant neighbour counts): dead items in the last chunk
+    (16, 5, 21, 18, 2, 1, "random"),         # D < 8
+    (64, 20, 17, 29, 3, 2, "full_range"),
+    (64, 64, 12, 20, 2, 1, "full_range"),    # the largest hypothesis count
 ]
 
 
@@ -163,6 +167,10 @@ def test_views_source_maps_of_another_size():
     (64, 48, 19, 27, 2, 2, "full_range"),   # ragged tiles, batch of two
     (64, 48, 13, 21, 2, 1, "random"),
     (64, 48, 14, 19, 2, 1, "behind"),
+    (64, 64, 24, 40, 5, 1, "full_range"),   # D = 64 = 48 + 16 propagated: what the cascade launches
+    (64, 52, 15, 33, 2, 1, "full_range"),   # D % 8 != 0
+    (32, 24, 21, 35, 2, 1, "full_range"),   # PixelwiseNet at another stage's width (the ABI allows it)
+    (16, 16, 18, 30, 2, 1, "sorted_band"),
 ])
 def test_pixelwise_matrix_core_matches_streaming(C, D, h, w, N, B, hyp):
     _, ops = _gpu()
@@ -170,22 +178,41 @@ def test_pixelwise_matrix_core_matches_streaming(C, D, h, w, N, B, hyp):
     _compare(ops, case, C, pixelwise=True, label=f"pixelwise C{C} D{D} {h}x{w} N{N} B{B} {hyp}")
 
 
-def test_uncovered_shapes_take_the_streaming_kernel():
-    """D = 12 (variant neighbour counts) is not a matrix-core shape: both settings must give the same bits."""
-    _, ops = _gpu()
-    case = _case(32, 12, 19, 33, 2, 1, "sorted_band", seed=3)
-    sim_mlp, pix_mlp = _mlp(1), _mlp(2)
-    a = _run(ops, "stream", case, 32, False, sim_mlp, pix_mlp)
-    b = _run(ops, "mfma", case, 32, False, sim_mlp, pix_mlp)
-    assert torch.equal(a["cost"], b["cost"]) and torch.equal(a["sim"], b["sim"])
-
-
 def test_fullsize_shapes_match_streaming():
     """BASELINE cfg-2 launch shapes (1600x1200, N=5) on smooth hypotheses."""
     _, ops = _gpu()
-    for C, D, scale, pixelwise, hyp in [(64, 48, 8, True, "full_range"), (64, 32, 8, False, "sorted_band"),
+    for C, D, scale, pixelwise, hyp in [(64, 64, 8, True, "full_range"), (64, 32, 8, False, "sorted_band"),
                                         (32, 16, 4, False, "sorted_band"), (16, 8, 2, False, "sorted_band")]:
         case = _case(C, D, 1200 // scale, 1600 // scale, 5, 1, hyp, seed=scale, pixelwise=pixelwise)
         _compare(ops, case, C, pixelwise=pixelwise, label=f"fullsize C{C} D{D}")
         del case
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", ["default", "variant"])
+def test_cascade_on_reference_features_with_the_matrix_core_kernel(case):
+    """The whole cascade on the reference's own features and noise, every pmn_warp_correlate launch on the matrix cores, against
+    the reference's per-iteration and final depths (tests/golden, generated by the imported reference): the 1e-3 relative bar of
+    the product's test_cascade_with_reference_features."""
+    P, ops = _gpu()
+    import goldenutil as GU
+    g, params, kw = GU.load_case(case)
+    model = P.PatchmatchNet(**kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    model = model.cuda().eval()
+    nv = int(g["n_views"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    feats = [{s: t(g[f"feature_{v}_s{s}"]) for s in (1, 2, 3)} for v in range(nv)]
+    ops.set_tuning(ops.TUNE_FLAGS, ops.FLAG_MFMA)
+    try:
+        with torch.no_grad():
+            depth, conf, dpm = model([t(g[f"image_{v}"]) for v in range(nv)], t(g["intrinsics"]), t(g["extrinsics"]),
+                                     t(g["depth_min"]), t(g["depth_max"]), noise=t(g["noise"]), features=feats)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_FLAGS, ops.DEFAULT_FLAGS)
+    for stage in (3, 2, 1):
+        for it in range(1, kw["patchmatch_iteration"][stage - 1] + 1):
+            e = GU.rel_err(dpm[stage][it - 1].cpu().numpy(), g[f"s{stage}_it{it}_depth_out"])
+            assert e < 1e-3, (stage, it, e)
+    assert GU.rel_err(depth.cpu().numpy(), g["depth"]) < 1e-3
