@@ -112,7 +112,104 @@ def make_samples(n_samples, n_views, H, W, device, rank, scene="surface"):
     return samples
 
 
-def cpu_baseline(H, W, n_src, model_kw):
+def reference_archive():
+    """oracle/_ref/patchmatchnet_reference.pt: the REFERENCE's own PatchmatchNet (unmodified models/net.py + params_000007.ckpt) as a
+    TorchScript archive, written by oracle/make_ref.py where the reference checkout exists (build()); test infrastructure, loaded
+    only by the baseline legs below.  None when it was never built."""
+    path = os.path.join(ROOT, "oracle", "_ref", "patchmatchnet_reference.pt")
+    return path if os.path.isfile(path) else None
+
+
+def reference_inputs(H, W, n_src, seed=0):
+    """One sample of the bench scene in the reference's own argument form (images: list of [1,3,H,W]; cameras [1,V,...])."""
+    import synth
+    imgs, intr, extr, _ = synth.render_scene(n_src + 1, H, W, seed=seed)
+    return ([im.contiguous() for im in imgs], torch.from_numpy(intr), torch.from_numpy(extr),
+            torch.tensor([425.0]), torch.tensor([935.0]))
+
+
+def reference_cpu_baseline(H, W, n_src, timed=3, warmup=2):
+    """The REAL reference on the host cores (SURVEY 8(d) last row; reference eval.py:44-70): `warmup` untimed (the
+    TorchScript executor profiles on its first call and specialises on its second) + `timed` forwards of the archive, median.  Threads: min(64, cores) -- on the 256-thread bench box torch's CPU backend is
+    slower with every hardware thread than with 32-64 (measured on the port: 3.8 s at 8, 5.2 s at 64, 84.6 s at 256)."""
+    path = reference_archive()
+    if path is None:
+        return None
+    cores = os.cpu_count() or 1
+    threads = min(64, cores)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        model = torch.jit.load(path, map_location="cpu").eval()
+        args = reference_inputs(H, W, n_src)
+        times = []
+        with torch.no_grad():
+            for i in range(warmup + timed):
+                torch.manual_seed(1234)
+                t0 = time.perf_counter()
+                model(*args)
+                times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    med = float(np.median(times[warmup:]))
+    return {"value": round(1.0 / med, 4), "unit": "depth-maps/s (whole PatchmatchNet.forward; same unit as `value`)",
+            "cores": threads, "kind": "reference",
+            "sample": f"the reference's own TorchScript archive (oracle/make_ref.py: unmodified models/net.py + params_000007.ckpt), "
+                      f"torch {torch.__version__} CPU backend, {threads} threads of {cores}; {warmup} warm-up ("
+                      + ", ".join(f"{t:.2f}" for t in times[:warmup]) + f" s) + {timed} timed "
+                      f"forwards at {W}x{H}, N={n_src}, iters (1,2,2) on the bench scene (seed 0): "
+                      + ", ".join(f"{t:.2f}" for t in times[warmup:]) + f" s, median {med:.2f} s",
+            "seconds": [round(t, 3) for t in times]}
+
+
+def reference_rocm_baseline(H, W, n_src, device, ours, warmup=3, timed=10, budget_s=240.0):
+    """The reference on THIS GPU through PyTorch-ROCm -- the denominator of the north star's '>= 4x the reference eval.py' (BASELINE.md
+    3.2; reference eval.py:37-41, 57-70): the same archive moved to the device, `warmup` untimed forwards (MIOpen's first-use
+    searches), `timed` forwards each bracketed by torch.cuda.synchronize(), median.  `ours` = this engine's model: its depth on the same
+    sample and the same seeded stage-3 draw is compared with the reference's (free-running, end to end)."""
+    path = reference_archive()
+    if path is None:
+        return None
+    out = {"kind": "reference on PyTorch-ROCm (TorchScript archive of the unmodified reference, oracle/make_ref.py)"}
+    try:
+        model = torch.jit.load(path, map_location=device).eval()
+        imgs, intr, extr, dmin, dmax = reference_inputs(H, W, n_src)
+        args = ([im.to(device) for im in imgs], intr.to(device), extr.to(device), dmin.to(device), dmax.to(device))
+        times, ref_depth = [], None
+        t_begin = time.perf_counter()
+        with torch.no_grad():
+            for i in range(warmup + timed):
+                torch.manual_seed(1234)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                depth, conf, _ = model(*args)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                ref_depth = depth
+                if time.perf_counter() - t_begin > budget_s and i + 1 >= warmup + 3:
+                    break
+            torch.manual_seed(1234)
+            mine, _, _ = ours([im for im in args[0]], args[1].clone(), args[2], args[3], args[4])
+            torch.cuda.synchronize()
+        tt = times[warmup:]
+        med = float(np.median(tt))
+        rel = ((mine - ref_depth).abs() / ref_depth.abs()).flatten().double()
+        out.update({"value": round(1.0 / med, 3), "unit": "depth-maps/s", "ms_per_forward": round(med * 1e3, 2), "samples": len(tt),
+                    "warmup_seconds": [round(t, 2) for t in times[:warmup]],
+                    "min_ms": round(min(tt) * 1e3, 2), "max_ms": round(max(tt) * 1e3, 2),
+                    "parity_vs_this_engine": {
+                        "what": "final depth of this engine vs the reference's on the same sample and the same seeded stage-3 draw, "
+                                "both free-running on this GPU (relative difference)",
+                        "p50": float(rel.median()), "p99": float(torch.quantile(rel[:: max(1, rel.numel() // 1000000)], 0.99)),
+                        "frac_gt_1e-3": float((rel > 1e-3).double().mean()), "max": float(rel.max())}})
+        del model
+        torch.cuda.empty_cache()
+    except Exception as e:  # the baseline must never take the bench line down
+        out["error"] = f"{type(e).__name__}: {str(e).splitlines()[0][:200] if str(e) else ''}"
+    return out
+
+
+def cpu_baseline(H, W, n_src, model_kw, thread_counts=(8, 32, 64)):
     """The whole forward on the host cores, in the metric's unit: FeatureNet.forward / Refinement.forward = the plain torch modules
     of patchmatchnet_amd/net.py on the CPU backend (reference models/net.py:9-122), cascade + confidence epilogue = the CPU oracle
     (a port of models/patchmatch.py, models/module.py:130-196, models/net.py:221-299).  One forward per thread count."""
@@ -149,8 +246,9 @@ def cpu_baseline(H, W, n_src, model_kw):
     prev = torch.get_num_threads()
     runs = {}
     # (all 256 hardware threads of the bench box: 84.6 s per forward against 4.3 s on 8 -- oversubscribed OpenMP + torch pools; the
-    #  sweep stops at 64 so that the default bench run stays within minutes)
-    for th in sorted({min(8, cores), min(32, cores), min(64, cores)}):
+    #  sweep stops at 64 so that the default bench run stays within minutes; with the reference archive timed beside it -- round 4 --
+    #  the port keeps one thread count)
+    for th in sorted({min(t, cores) for t in thread_counts}):
         dt, parts = forward(th)
         runs[th] = {"seconds": round(dt, 2), "depth_maps_per_s": round(1.0 / dt, 4),
                     "featurenet_cascade_refinement_s": [round(x, 2) for x in parts]}
@@ -162,9 +260,7 @@ def cpu_baseline(H, W, n_src, model_kw):
                       f"threads -> seconds: " + ", ".join(f"{th}: {r['seconds']}" for th, r in runs.items()) +
                       f"; host has {cores} hardware threads; FeatureNet / Refinement = torch CPU backend, cascade = C/OpenMP oracle",
             "threads": {str(th): r for th, r in runs.items()},
-            "reference_measured_elsewhere": REFERENCE_CPU_MEASURED,
-            "rocm_reference_denominator": "unmeasurable on the bench box: the north star's '>= 4x the reference on PyTorch-ROCm' needs "
-                                          "the reference sources, which cannot travel (DESIGN.md section 4)"}
+            "reference_measured_elsewhere": REFERENCE_CPU_MEASURED}
 
 
 def self_launch(n_ranks):
@@ -438,13 +534,16 @@ def main():
         # scripts/make_traffic_json.py for the collection + gfx950 FETCH_SIZE correction); null when not available
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        traffic_note = "HBM bytes per step over the same launches (rocprofv3 PMC, profiles/pmc_traffic.json)"
+        traffic_note = ("HBM bytes per step over the same launches: a COMMITTED measurement (rocprofv3 PMC passes, profiles/pmc_traffic.json, "
+                        "stamped with the hash of the kernel sources it was taken on), not a counter read of this run")
         tj = json.load(open(tpath)) if os.path.isfile(tpath) else None
         if tj is not None and tj.get("kernel_source_sha256") != warp_kernel_source_hash():
             traffic_note = "null: profiles/pmc_traffic.json was measured on different kernel sources (hash mismatch) -- re-collect"
             tj = None
-        if tj is not None and (H, W, n_src) == (1200, 1600, 5):
-            tk = tj["kernels"]
+        tk = None if tj is None else tj.get("configs", {}).get(f"{W}x{H}_N{n_src}", {}).get("kernels")
+        if tj is not None and tk is None:
+            traffic_note = f"null: profiles/pmc_traffic.json has no passes for {W}x{H}_N{n_src} (scripts/gpu_pmc_traffic.sh)"
+        if tk is not None:
             try:
                 per_step = 0
                 for ms, nb, tag in recs[:len(recs) // sampled]:
@@ -453,12 +552,14 @@ def main():
                 traffic = per_step
             except KeyError:
                 traffic = None
+        baseline_config = {(1200, 1600, 5): "BASELINE configs[1]", (1056, 1920, 7): "BASELINE configs[2]",
+                           (2048, 3072, 10): "BASELINE configs[4], one GPU's share"}.get((H, W, n_src), "not a BASELINE config")
         line = {
-            "metric": "depth-maps/sec at 1600x1200 N=5 src views", "value": round(value, 4), "unit": "depth-maps/s",
+            "metric": f"depth-maps/sec at {W}x{H} N={n_src} src views", "value": round(value, 4), "unit": "depth-maps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
-                                   f"(BASELINE configs[1]); ref views sharded 1/rank", "weights": weights,
+                                   f"({baseline_config}); ref views sharded 1/rank", "weights": weights,
                        "distinct_samples": len(samples),
                        "arithmetic": "fp32 results throughout; FeatureNet's conv1..conv10 run on the fp16 matrix cores with SPLIT operands "
                                      "(x = hi + lo/2048, three exact-product MFMAs, fp32 accumulation): 2-4e-7 of the output scale, the error of "
@@ -495,7 +596,22 @@ def main():
                                        for k, v in per.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(H, W, n_src, DEFAULT_KW)
+            # round 4: the REAL reference timed on this box -- host cores (kind "reference") and, through PyTorch-ROCm, this GPU (the
+            # denominator of the north star's 4x); the CPU port of rounds 1-3 stays beside it at one thread count
+            ref_cpu = reference_cpu_baseline(H, W, n_src)
+            port = cpu_baseline(H, W, n_src, DEFAULT_KW, thread_counts=(32,) if ref_cpu else (8, 32, 64))
+            if ref_cpu is not None:
+                ref_cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "sample")}
+                line["cpu_baseline"] = ref_cpu
+            else:
+                port["note"] = "oracle/_ref/patchmatchnet_reference.pt was never built (python oracle/make_ref.py needs the reference checkout)"
+                line["cpu_baseline"] = port
+            ref_gpu = reference_rocm_baseline(H, W, n_src, device, model)
+            if ref_gpu is not None:
+                if "value" in ref_gpu:
+                    ref_gpu["this_engine_over_reference"] = round(value / ref_gpu["value"], 2)
+                    ref_gpu["this_engine_single_stream_over_reference"] = round((R / eager_elapsed) / ref_gpu["value"], 2)
+                line["reference_rocm"] = ref_gpu
         print(json.dumps(line), flush=True)
     if launched:
         dist.barrier()

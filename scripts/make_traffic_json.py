@@ -19,6 +19,7 @@ sys.path.insert(0, root)
 from bench import warp_kernel_source_hash  # noqa: E402  (bench.py refuses a traffic file whose hash is not the tree's)
 
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc_win")
+config = sys.argv[3] if len(sys.argv) > 3 else "1600x1200_N5"  # WxH_N<source views>: the bench configuration the passes ran
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
@@ -36,9 +37,19 @@ for k, v in vals.items():
         wk = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
         out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "pmc_traffic.json")
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_traffic.sh) over bench.py --eager: the "
-                     "pmn_warp_correlate launches of real forwards on the bench's samples (cfg-2), averaged per kernel shape",
+doc = {}
+if os.path.isfile(dst):
+    try:
+        doc = json.load(open(dst))
+    except ValueError:
+        doc = {}
+if doc.get("kernel_source_sha256") != warp_kernel_source_hash() or "configs" not in doc:
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_traffic.sh) over bench.py --eager: the "
+                     "pmn_warp_correlate launches of real forwards on the bench's samples, averaged per kernel shape, one entry per "
+                     "bench configuration (WxH_N<source views>)",
            "kernel_source_sha256": warp_kernel_source_hash(),
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE under-reports wide reads by 2x)",
-           "kernels": out}, open(dst, "w"), indent=1)
-print(json.dumps(out, indent=1))
+           "configs": {}}
+doc["configs"][config] = {"kernels": out}
+json.dump(doc, open(dst, "w"), indent=1)
+print(config, json.dumps(out, indent=1))
