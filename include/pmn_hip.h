@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 16
+#define PMN_ABI_VERSION 17
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -138,33 +138,28 @@ int pmn_fpn_tail(const float *x, const float *up, const float *w_in, const float
  * (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain).  in [N,H,W,cin] channels-last; weights DEVICE float
  * [K*K][cin/8][coutp/32][64][4] with coutp = cout rounded up to 32 (patchmatchnet_amd/params.py: pack_conv_mfma); shift
  * DEVICE float[coutp].
- *   planar == 0  FeatureNet's wide layers conv5..conv10 (reference models/net.py:25-34): out [N,Ho,Wo,cout] channels-last,
- *                out_b NULL, ca == cout, dil 1; supported (cin,cout,K,stride): (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2);
- *                plus the 1x1 form (64, cout <= 128, 1, 1) with channels [0,ca) -> out [N,H,W,ca], [ca,cout) -> out_b [N,H,W,cout-ca]
- *                (the 1/8-resolution level of the folded FPN head, same arithmetic as pmn_fpn_level)
- *   planar == 1  the offset heads propa_conv + eval_conv of one stage as ONE dilated 3x3 convolution over the reference feature
- *                (models/patchmatch.py:288-311): channels [0,ca) -> out [N,ca,Ho,Wo], [ca,cout) -> out_b [N,cout-ca,Ho,Wo]
- *                (NULL when ca == cout), both planar; K 3, stride 1, pad == dil; supported (cin,dil): (64,2), (32,4), (16,6),
- *                cout <= 64 (other dilations: pmn_conv2d). */
+ *   planar == 0  the 1x1 form (cin 64, cout <= 128, K 1, stride 1, pad 0): channels [0,ca) -> out [N,H,W,ca], [ca,cout) -> out_b
+ *                [N,H,W,cout-ca] -- the 1/8-resolution level of the folded FPN head (reference models/net.py:36-70), same arithmetic
+ *                as pmn_fpn_level.  This is the ONLY shape of the product library since round 4 (ABI 17): everything else returns
+ *                PMN_ERR_SHAPE.  The research build (pmn_hip_experimental.h) additionally keeps rounds 1-2's forms: FeatureNet's wide
+ *                layers (cin,cout,K,stride) = (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2) with out [N,Ho,Wo,cout], and
+ *   planar == 1  the offset heads of one stage as ONE dilated 3x3 convolution ((cin,dil) = (64,2), (32,4), (16,6), cout <= 64;
+ *                channels [0,ca) -> out [N,ca,Ho,Wo], the rest -> out_b, planar) -- superseded by pmn_conv2d_f16s /
+ *                pmn_offset_heads_f16s in round 3. */
 int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, float *out, float *out_b, int N, int H, int W,
                     int cin, int cout, int ca, int K, int stride, int pad, int dil, int relu, int planar, void *stream);
 
-/* Winograd F(2x2,3x3) form of FeatureNet's 3x3 stride-1 ConvBnReLU layers with cin == cout == C in {16, 32, 64} (conv3/4, conv6/7,
- * conv9/10; reference models/net.py:21-31) on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): 16 instead of 36 multiplies per 2x2
- * output tile and input channel, same fp32 error level as the direct form (scripts/winograd_study.py).  in / out [N,H,W,C]
- * channels-last; weights DEVICE float [C/16][16][C/16][64][4] = G g G^T with the BatchNorm scale folded in, computed in float64 and
- * laid out in matrix-operand lane order (patchmatchnet_amd/params.py: pack_conv_wino); shift DEVICE float[C]. */
-int pmn_conv3x3_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int C, int relu,
-                     void *stream);
-
-/* Winograd form of FeatureNet's 5x5 stride-2 ConvBnReLU layers conv2 (8->16), conv5 (16->32), conv8 (32->64) (reference
- * models/net.py:20, 24, 28): the stride-2 convolution is split into four stride-1 convolutions on the parity sub-images (3x3, 3x2, 2x3,
- * 2x2 taps), each in minimal-filtering form F(2,3) / F(2,2) per dimension: 49 instead of 100 multiplies per 2x2 output tile and input
- * channel, on v_mfma_f32_16x16x4_f32.  in [N,H,W,cin] channels-last; weights DEVICE float [cin/8][49][cout/16][64][2]
- * (patchmatchnet_amd/params.py: pack_conv5x5s2_wino, transforms in float64, BatchNorm scale folded in); shift DEVICE float[cout];
- * out [N,(H-1)/2+1,(W-1)/2+1,cout].  Supported (cin,cout): (8,16), (16,32), (32,64). */
-int pmn_conv5x5s2_wino(const float *in, const float *weights, const float *shift, float *out, int N, int H, int W, int cin,
-                       int cout, int relu, void *stream);
+/* ---- fp16-split entry points (pmn_conv2d_f16s, pmn_offset_heads_f16s, pmn_stem_f16s, pmn_refine_fused): accepted magnitudes ----
+ * Every activation and weight x is split as hi = fp16(x), lo = fp16((x - hi) * 2048) and the product sum is taken as
+ * hi*hi + (hi*lo + lo*hi) / 2048 with fp32 accumulation.  That reproduces an fp32 convolution (2-4e-7 of the output scale) for
+ *     6.1e-5 <= |x| < 65504   (fp16's normal range: 22 significant bits per factor);
+ * below 6.1e-5 `hi` is a subnormal (absolute error <= 3e-8 per factor -- irrelevant next to factors of normal size; an operand
+ * tensor that is ENTIRELY below 1e-6 loses relative precision); at |x| >= 65504 `hi` becomes +-inf and the output is inf / NaN where
+ * an fp32 convolution is finite.  The kernels do not check.  WEIGHTS are checked on the host when they are packed
+ * (patchmatchnet_amd/params.py raises F16DomainError for a BatchNorm-folded weight outside (-65504, 65504), and the modules then use
+ * the fp32 kernels pmn_stem / pmn_conv2d / pmn_refine_front + pmn_refine_tail and say so); ACTIVATIONS are the caller's contract:
+ * images in [0, 1] (or any range below 6e4) and the reference checkpoint keep every intermediate below 1e2.
+ * tests/test_hip_parity.py::test_f16_split_domain documents both ends of the range on the GPU. */
 
 /* FeatureNet's ConvBnReLU layers conv2..conv10 (reference models/net.py:20-31: 3x3 stride 1 with cin == cout in {16,32,64}; 5x5
  * stride 2 with (cin,cout) in {(8,16),(16,32),(32,64)}) on the FP16 matrix cores with SPLIT operands: every activation and every
@@ -182,7 +177,7 @@ int pmn_conv2d_f16s(const float *in, const void *weights, const float *shift, fl
  * in [N,H,W,cin] channels-last; weights DEVICE float16 [cin/16][k-steps][coutp/16][2][64][8] with coutp = cout rounded up to 16
  * (patchmatchnet_amd/params.py pack_offset_heads_f16s); shift DEVICE float[coutp]; out_a [N,ca,H,W] = channels [0,ca), out_b
  * [N,cout-ca,H,W] = the rest (NULL when ca == cout).  Supported (cin, dilation): (64,2), (32,4), (16,6) -- the reference's three stages
- * -- with cout <= 64; PMN_ERR_SHAPE otherwise (the caller then uses pmn_conv2d_mfma / pmn_conv2d). */
+ * -- with cout rounded up to 32, 48 or 64; PMN_ERR_SHAPE otherwise (the caller then uses pmn_conv2d). */
 int pmn_offset_heads_f16s(const float *in, const void *weights, const float *shift, float *out_a, float *out_b, int N, int H, int W,
                           int cin, int cout, int ca, int dil, void *stream);
 

@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -40,8 +40,6 @@ SIGNATURES = {
     "pmn_conv2d": [_fp, _fp, _fp, _fp, _fp] + [_i] * 14 + [_s],
     "pmn_fpn_tail": [_fp] * 6 + [_i] * 6 + [_s],
     "pmn_fpn_level": [_fp] * 6 + [_i] * 6 + [_s],
-    "pmn_conv3x3_wino": [_fp] * 4 + [_i] * 5 + [_s],
-    "pmn_conv5x5s2_wino": [_fp] * 4 + [_i] * 6 + [_s],
     "pmn_conv2d_f16s": [_fp] * 4 + [_i] * 8 + [_s],
     "pmn_offset_heads_f16s": [_fp] * 5 + [_i] * 7 + [_s],
     "pmn_refine_front": [_fp] * 7 + [_i] * 3 + [_s],
@@ -57,7 +55,9 @@ SIGNATURES = {
 }
 
 # libpmn_hip_experimental.so only (include/pmn_hip_experimental.h; `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`)
-EXPERIMENTAL_SIGNATURES = {"pmn_set_tuning": [_i, _i]}
+EXPERIMENTAL_SIGNATURES = {"pmn_set_tuning": [_i, _i],
+                           "pmn_conv3x3_wino": [_fp] * 4 + [_i] * 5 + [_s],
+                           "pmn_conv5x5s2_wino": [_fp] * 4 + [_i] * 6 + [_s]}
 EXPERIMENTAL_LIB_PATH = os.path.join(_CSRC, "libpmn_hip_experimental.so")
 
 

@@ -199,11 +199,11 @@ static int launch_mfma(const float* in, const float* w, const float* shift, floa
 
 // in [N,H,W,cin] channels-last; weights DEVICE float [K*K][cin/8][coutp/32][64][4] (params.pack_conv_mfma; coutp = cout rounded
 // up to 32, BatchNorm scale folded in); shift DEVICE float[coutp].
-//   planar == 0: out [N,Ho,Wo,cout] channels-last (out_b NULL, ca == cout == coutp, dil == 1); supported (cin,cout,K,stride):
-//                (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2); and (64, <=128, 1, 1) with the channels split between
-//                out [N,H,W,ca] and out_b [N,H,W,cout-ca]
-//   planar == 1: out [N,ca,Ho,Wo] and out_b [N,cout-ca,Ho,Wo] (NULL when ca == cout) planar; K = 3, stride 1, pad == dil;
-//                supported (cin,dil): (64,2), (32,4), (16,6) with cout <= 64 -- the offset heads of the default cascade
+//   planar == 0: (64, <=128, 1, 1) with the channels split between out [N,H,W,ca] and out_b [N,H,W,cout-ca] -- the only form of the
+//                product library; research build (PMN_EXPERIMENTAL) also: out [N,Ho,Wo,cout] channels-last (out_b NULL, ca == cout ==
+//                coutp, dil == 1) for (cin,cout,K,stride) = (64,64,3,1), (32,32,3,1), (32,64,5,2), (16,32,5,2)
+//   planar == 1: research build only: out [N,ca,Ho,Wo] and out_b [N,cout-ca,Ho,Wo] (NULL when ca == cout) planar; K = 3, stride 1,
+//                pad == dil; (cin,dil): (64,2), (32,4), (16,6) with cout <= 64 -- the offset heads of the default cascade
 extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const float* shift, float* out, float* out_b, int N,
                                int H, int W, int cin, int cout, int ca, int K, int stride, int pad, int dil, int relu,
                                int planar, void* stream) {
@@ -221,6 +221,13 @@ extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const floa
         // 1x1, 64 -> (ca | cout-ca) <= 128 channels: the 1/8-resolution level of the folded FPN head (pmn_fpn_level's arithmetic)
         if (cin == 64 && K == 1 && stride == 1 && pad == 0 && cout <= 128)
             return launch_mfma<64, 64, 128, 1, 1, 1, 4, 1, 4, false>(in, weights, shift, out, out_b, a, st);
+#ifndef PMN_EXPERIMENTAL
+        return PMN_ERR_SHAPE;  // the product library carries the 1x1 form alone (the folded FPN head's 1/8 level)
+    }
+    return PMN_ERR_SHAPE;
+}
+#else  // research build: rounds 1-2's fp32 matrix-core forms of FeatureNet's wide layers and of the offset heads (superseded by
+       // pmn_conv2d_f16s / pmn_offset_heads_f16s in round 3; tests/test_hip_parity.py runs them under PMN_EXPERIMENTAL=1)
         if (ca != cout) return PMN_ERR_SHAPE;
 #define PMN_MFMA(CI, CCH, CO, KK, SS, NWV, PGV, DD) return launch_mfma<CI, CCH, CO, KK, SS, 1, NWV, PGV, DD, false>(in, weights, shift, out, out_b, a, st)
         // NW = 4 waves x one 32-pixel group each (8x16-pixel tiles): one wave per SIMD per workgroup, 80-128 VGPRs; measured
@@ -244,3 +251,4 @@ extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const floa
 #undef PMN_HEAD
     return PMN_ERR_SHAPE;
 }
+#endif

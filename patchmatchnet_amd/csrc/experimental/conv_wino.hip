@@ -20,7 +20,8 @@
 //   B operand  U repacked on the host to [chunk][pos][cout block][64 lanes][4]: one contiguous 1 KB load per wave, positions
 //              run 4 deep ahead in a register ring
 //   C/D        16x16 MFMA: lane holds column (lane&15) = output channel, rows 4*(lane>>4) + r = tiles
-#include "pmn_common.hpp"
+#include "../pmn_common.hpp"
+#include "../../../include/pmn_hip_experimental.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -25,7 +25,7 @@
 //   * lane = (n = lane & 15, k = lane >> 4); lane (n, k) owns the two hypotheses d = 8 chunk + 2 k + {0, 1} of pixel n (its
 //     `items`, carried in the halves of packed registers).  Hypotheses are sorted along d, so a chunk's taps sit on a short
 //     piece of the epipolar line; tiles never straddle image rows.
-//   * per view: every lane projects its items (same arithmetic as the streaming kernel: v_rcp + one Newton step); a
+//   * per view: every lane projects its items (same arithmetic as the streaming kernel: pmn_pose_position); a
 //     wave reduction gives the bounding box of the live taps = the window (Wd x Hd texels, flattened row-major: texel q).
 //   * software pipeline: the window of the NEXT fill (next pass / next view: projected first) is requested before the
 //     current one is consumed, so its L2 latency hides behind the MFMAs and the gather of the current one.
@@ -233,30 +233,22 @@ __global__ __launch_bounds__(PIXELWISE ? 512 : 64 * NW) __attribute__((amdgpu_wa
         dep[i] = dok[i] ? a.depth[((size_t)b * D + d0 + i) * hw + p] : 0.0f;
     }
 
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
     const int wv = w >> a.vw_shift, hwv = (h >> a.vw_shift) * wv;
     const int vw_idx = (y >> a.vw_shift) * wv + (min(x, w - 1) >> a.vw_shift);
     const unsigned pixbase = (unsigned)n * PP;
 
     // ---- projection of the lane's items into view v + the window of the wave's live taps ---------------------------------
     auto prepare = [&](CmTask& T, const int v) __attribute__((always_inline)) {
-        const float* P = plds + v * 16;
-        const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx = P[3] * sxs;
-        const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty = P[7] * sys;
-        const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+        const PmnPose pose = pmn_make_pose(plds + v * 16, xf, yf);  // the reference's own warp chain (pmn_common.hpp)
         int lox = 0x7fffffff, loy = 0x7fffffff, hix = -0x7fffffff, hiy = -0x7fffffff;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float dp = dep[i];
-            const float pz = fmaf(rz, dp, tz);
             PmnTapsXY t;
             t.x0 = t.y0 = 0;
             t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
-            if (dok[i] && pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
-                float inv = __builtin_amdgcn_rcpf(pz);
-                inv = inv * fmaf(-pz, inv, 2.0f);
-                t = cm_taps_xy(fmaf(rx, dp, tx) * inv, fmaf(ry, dp, ty) * inv, hs, ws);
-            }
+            float ix, iy;
+            // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
+            if (pmn_pose_position(pose, dep[i], h, w, hs, ws, ix, iy) && dok[i]) t = cm_taps_xy(ix, iy, hs, ws);
             T.x0[i] = t.x0; T.y0[i] = t.y0;
             T.w00[i] = t.w00; T.w01[i] = t.w01; T.w10[i] = t.w10; T.w11[i] = t.w11;
             T.live[i] = (t.w00 + t.w01) + (t.w10 + t.w11) > 0.0f;  // items without an in-range corner stay out of the window

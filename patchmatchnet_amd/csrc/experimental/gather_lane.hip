@@ -90,30 +90,18 @@ __device__ __forceinline__ float lane_blend_dot(const pmn_f4 t00, const pmn_f4 t
     return fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
 }
 
-struct LanePose {  // p(d) = r * d + t for this lane's pixel and one view (source-map scale folded in, as gather_corr.hip)
-    float rx, ry, rz, tx, ty, tz;
-};
+using LanePose = PmnPose;  // the reference's own warp chain (pmn_common.hpp): round 4 replaced the v_rcp projection everywhere
 
-__device__ __forceinline__ LanePose lane_make_pose(const float* __restrict__ P, float xf, float yf, float sxs, float sys) {
-    LanePose q;
-    q.rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs;
-    q.tx = P[3] * sxs;
-    q.ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys;
-    q.ty = P[7] * sys;
-    q.rz = fmaf(P[8], xf, P[9] * yf) + P[10];
-    q.tz = P[11];
-    return q;
+__device__ __forceinline__ LanePose lane_make_pose(const float* __restrict__ P, float xf, float yf, float, float) {
+    return pmn_make_pose(P, xf, yf);
 }
 
 // Tap record of one item.  The general path is gather_corr.hip's (behind-camera sentinel, module.py:166-169; border handling
 // of pmn_axis).  When EVERY lane of the wave is an interior item (both low corners in [0, size-2]: the 4 taps exist at their
 // natural slots) the selects of pmn_axis are skipped -- same floor / weight expressions, same values.
-__device__ __forceinline__ bool lane_project(const LanePose& q, float dep, bool active, int hs, int ws, PmnTapsXY& t) {
-    const float pz = fmaf(q.rz, dep, q.tz);
-    float inv = __builtin_amdgcn_rcpf(pz);
-    inv = inv * fmaf(-pz, inv, 2.0f);
-    const float ix = fmaf(q.rx, dep, q.tx) * inv, iy = fmaf(q.ry, dep, q.ty) * inv;
-    const bool front = active && pz > 1e-3f;
+__device__ __forceinline__ bool lane_project(const LanePose& q, float dep, bool active, int h, int w, int hs, int ws, PmnTapsXY& t) {
+    float ix, iy;
+    const bool front = pmn_pose_position(q, dep, h, w, hs, ws, ix, iy) && active;
     const bool interior = front && ix >= 0.0f && ix < (float)(ws - 1) && iy >= 0.0f && iy < (float)(hs - 1);
     if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
 #pragma clang fp contract(off)
@@ -366,7 +354,7 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
                 PmnTapsXY t;
                 t.x0 = 0; t.y0 = 0; t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
                 bool tv = false;
-                if (s < nd) tv = lane_project(q, rdep[s], ok, hs, ws, t);
+                if (s < nd) tv = lane_project(q, rdep[s], ok, h, w, hs, ws, t);
                 rx0[s] = t.x0;
                 ry0[s] = t.y0;
                 rw[s] = pmn_f4{t.w00, t.w01, t.w10, t.w11};
@@ -384,7 +372,7 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
             for (int s = 1; s < DCH; ++s)
                 if (s < nd) dlast = rdep[s];
             PmnTapsXY t;
-            if (lane_project(q, dlast, ok, hs, ws, t)) {
+            if (lane_project(q, dlast, ok, h, w, hs, ws, t)) {
                 lo_x = min(lo_x, t.x0); hi_x = max(hi_x, t.x0);
                 lo_y = min(lo_y, t.y0); hi_y = max(hi_y, t.y0);
             }
@@ -418,7 +406,7 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
                     if (s < nd) {
                         if (!STORE && s > 0) {
                             PmnTapsXY t;
-                            if (lane_project(q, rdep[s], ok, hs, ws, t)) tvmask |= 1u << s;
+                            if (lane_project(q, rdep[s], ok, h, w, hs, ws, t)) tvmask |= 1u << s;
                             rx0[s] = t.x0;
                             ry0[s] = t.y0;
                             rw[s] = pmn_f4{t.w00, t.w01, t.w10, t.w11};

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
 #pragma unroll
         for (int d = 0; d < DT; ++d) acc[sl][d] = 0.0f;
 
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
     const float xf = (float)pr_x, yf = (float)pr_y;
     const int wv = w >> a.vw_shift, hwv = (h >> a.vw_shift) * wv;
     const int wk_vw_idx = (wk_y >> a.vw_shift) * wv + (wk_x >> a.vw_shift);
@@ -184,10 +183,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
     // Tap records of the thread's hypotheses for view v, the tile's window (bounding box of every tap, cut down when it does not
     // fit a window buffer) and the records parked in record buffer `rb`.  Contains ONE workgroup barrier.
     auto prepare_view = [&](const int v, const int rb) -> Geom {
-        const float* P = a.proj + ((size_t)b * N + v) * 16;
-        const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx_ = P[3] * sxs;
-        const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty_ = P[7] * sys;
-        const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+        const PmnPose pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);  // the reference's own warp chain (round 4)
         PmnTapsXY rec[NR];
         bool rv[NR];
         int lo_x = BIG, hi_x = -BIG, lo_y = BIG, hi_y = -BIG;
@@ -198,12 +194,9 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
             t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
             bool valid = false;
             if (pr_ok && pr_d0 + 4 * j < nd) {
-                const float dep = rdep[j];
-                const float pz = fmaf(rz, dep, tz);
-                if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
-                    float inv = __builtin_amdgcn_rcpf(pz);
-                    inv = inv * fmaf(-pz, inv, 2.0f);
-                    t = pmn_make_taps_xy(fmaf(rx, dep, tx_) * inv, fmaf(ry, dep, ty_) * inv, hs, ws);
+                float ix, iy;
+                if (pmn_pose_position(pose, rdep[j], h, w, hs, ws, ix, iy)) {  // false: behind the camera, samples nothing
+                    t = pmn_make_taps_xy(ix, iy, hs, ws);
                     valid = true;
                 }
             }

@@ -86,34 +86,23 @@ __device__ __forceinline__ float blend_dot(const pmn_f4 t00, const pmn_f4 t01, c
     return fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
 }
 
-struct PosePix {  // p(d) = r * d + t for this lane's pixel and one view (source-map scale folded in, as gather_corr.hip)
-    float rx, ry, rz, tx, ty, tz;
-};
+using PosePix = PmnPose;  // the reference's own warp chain (pmn_common.hpp): round 4 replaced the v_rcp projection everywhere
 
-__device__ __forceinline__ PosePix make_pose_pix(const float* __restrict__ P, float xf, float yf, float sxs, float sys) {
-    PosePix q;
-    q.rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs;
-    q.tx = P[3] * sxs;
-    q.ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys;
-    q.ty = P[7] * sys;
-    q.rz = fmaf(P[8], xf, P[9] * yf) + P[10];
-    q.tz = P[11];
-    return q;
+__device__ __forceinline__ PosePix make_pose_pix(const float* __restrict__ P, float xf, float yf, float, float) {
+    return pmn_make_pose(P, xf, yf);
 }
 
 // Tap record of one item; returns false (zero weights, corner (0,0)) for an inactive lane or a hypothesis behind the source
 // camera (reference sentinel, module.py:166-169).
-__device__ __forceinline__ bool project_item(const PosePix& q, float dep, bool active, int hs, int ws, PmnTapsXY& t) {
+__device__ __forceinline__ bool project_item(const PosePix& q, float dep, bool active, int h, int w, int hs, int ws, PmnTapsXY& t) {
     t.x0 = 0;
     t.y0 = 0;
     t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
     bool tv = false;
     if (active) {
-        const float pz = fmaf(q.rz, dep, q.tz);
-        if (pz > 1e-3f) {
-            float inv = __builtin_amdgcn_rcpf(pz);
-            inv = inv * fmaf(-pz, inv, 2.0f);
-            t = pmn_make_taps_xy(fmaf(q.rx, dep, q.tx) * inv, fmaf(q.ry, dep, q.ty) * inv, hs, ws);
+        float ix, iy;
+        if (pmn_pose_position(q, dep, h, w, hs, ws, ix, iy)) {
+            t = pmn_make_taps_xy(ix, iy, hs, ws);
             tv = true;
         }
     }
@@ -324,12 +313,12 @@ __global__ __launch_bounds__(PMN_BLOCK, 3) void gather_win_views_kernel(const Ga
         pmn_glb_char* src_slice = (pmn_glb_char*)a.src + (((size_t)(v * a.B + b) * hs * ws) * (C * 4) + slice * 64);
         const float vw = ok ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
         PmnTapsXY ta, tb;
-        const bool va = project_item(q, rdep[0], ok, hs, ws, ta);
+        const bool va = project_item(q, rdep[0], ok, h, w, hs, ws, ta);
         float dlast = rdep[0];
 #pragma unroll
         for (int s = 1; s < DCH; ++s)
             if (s < nd) dlast = rdep[s];
-        const bool vb = project_item(q, dlast, ok, hs, ws, tb);
+        const bool vb = project_item(q, dlast, ok, h, w, hs, ws, tb);
         WinGeom g;
         if (dbg & 16) {  // ablation: no bounding-box reduction
             g.bx0 = max(min(ta.x0 - 8, ws - 34), 0); g.by0 = max(min(ta.y0 - 2, hs - 6), 0); g.bw = min(32, ws); g.bh = min(6, hs);
@@ -343,7 +332,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 3) void gather_win_views_kernel(const Ga
             if (s < nd) {
                 PmnTapsXY t = ta;
                 bool tv = va;
-                if (!(dbg & 4)) tv = project_item(q, rdep[s], ok, hs, ws, t);  // ablation bit 2: no per-item projection
+                if (!(dbg & 4)) tv = project_item(q, rdep[s], ok, h, w, hs, ws, t);  // ablation bit 2: no per-item projection
                 float dot[4], sim[GPS];
                 if (dbg & 2) {  // ablation bit 1: no taps
                     dot[0] = t.w00; dot[1] = t.w01; dot[2] = t.w10; dot[3] = t.w11;
@@ -492,8 +481,8 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_win_pixelwise_kernel(const G
             const float depa = la ? a.depth[((size_t)b * D + da) * hw + p] : 0.0f;
             const float depb = lb ? a.depth[((size_t)b * D + db) * hw + p] : 0.0f;
             PmnTapsXY ta, tb;
-            const bool va = project_item(q, depa, la, hs, ws, ta);
-            const bool vb = project_item(q, depb, lb, hs, ws, tb);
+            const bool va = project_item(q, depa, la, h, w, hs, ws, ta);
+            const bool vb = project_item(q, depb, lb, h, w, hs, ws, tb);
             const WinGeom g = make_window(ta, va, tb, vb, cap_texels, hs, ws);
             if (!(dbg & 1)) stage_window<C, 8>(win, src_slice, g, ws, lane);
             {

@@ -177,23 +177,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
     const bool owner = (lc % LPG) == 0;
     const int gB = lc / LPG;
 
-    // Homography coefficients of this thread's pixel for one view: p(d) = r * d + t with r = R [x y 1]^T.  The source map
-    // scale (ws-1)/(w-1) of the reference's normalise -> un-normalise round trip (module.py:170-181) is folded in.
-    // Positions are computed with v_rcp + one Newton step instead of the reference's chain of IEEE divisions: they agree
-    // with the reference's fp32 positions to ~1e-4 px (both carry that much rounding noise at 800-px coordinates).
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
-    struct Pose { float rx, ry, rz, tx, ty, tz; };
-    auto make_pose = [&](const float* P) {
-        Pose q;
-        const float x = (float)xA, y = (float)yA;
-        q.rx = (fmaf(P[0], x, P[1] * y) + P[2]) * sxs;
-        q.ry = (fmaf(P[4], x, P[5] * y) + P[6]) * sys;
-        q.rz = fmaf(P[8], x, P[9] * y) + P[10];
-        q.tx = P[3] * sxs;
-        q.ty = P[7] * sys;
-        q.tz = P[11];
-        return q;
-    };
+    // (the warp itself: pmn_make_pose / pmn_pose_position of pmn_common.hpp -- the reference's own IEEE chain)
+    using Pose = PmnPose;
+    auto make_pose = [&](const float* P) { return pmn_make_pose(P, (float)xA, (float)yA); };
 
     // phase A for one view / hypothesis range [d_lo, d_hi): records land at rec_base + (d - d_lo)*NPIX + pixA
     auto phase_a = [&](const Pose& q, int d_lo, int d_hi, int rec_base) {
@@ -214,15 +200,11 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
                     w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
                     off = t.off;
                 } else {
-                    const float dep = a.depth[((size_t)b * D + d) * hw + pA];
-                    const float pz = fmaf(q.rz, dep, q.tz);
-                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
-                        float inv = __builtin_amdgcn_rcpf(pz);
-                        inv = inv * fmaf(-pz, inv, 2.0f);
-                        const PmnTaps t = pmn_make_taps(fmaf(q.rx, dep, q.tx) * inv, fmaf(q.ry, dep, q.ty) * inv, hs, ws);
-                        w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
-                        off = t.off;
-                    }
+                    float ix, iy;
+                    pmn_pose_position(q, a.depth[((size_t)b * D + d) * hw + pA], h, w, hs, ws, ix, iy);
+                    const PmnTaps t = pmn_make_taps(ix, iy, hs, ws);
+                    w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
+                    off = t.off;
                 }
             }
             const int i = rec_base + (d - d_lo) * NPIX + pixA;
@@ -250,10 +232,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             rdep[j] = (okB && d < D) ? a.depth[((size_t)b * D + d) * hw + pB] : -1.0f;
         }
         for (int v = 0; v < N; ++v) {
-            const float* P = a.proj + ((size_t)b * N + v) * 16;
-            const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx = P[3] * sxs;
-            const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty = P[7] * sys;
-            const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);
             float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
             int roff[RPL];
 #pragma unroll
@@ -263,13 +242,10 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
                 t.off = 0;
                 t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
                 if (okB && d < D) {
-                    const float dep = rdep[j];
-                    const float pz = fmaf(rz, dep, tz);
-                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
-                        float inv = __builtin_amdgcn_rcpf(pz);
-                        inv = inv * fmaf(-pz, inv, 2.0f);
-                        t = pmn_make_taps(fmaf(rx, dep, tx) * inv, fmaf(ry, dep, ty) * inv, hs, ws);
-                    }
+                    // the reference's own IEEE chain (pmn_common.hpp); a behind-camera hypothesis lands outside every tap
+                    float ix, iy;
+                    pmn_pose_position(lane_pose, rdep[j], h, w, hs, ws, ix, iy);
+                    t = pmn_make_taps(ix, iy, hs, ws);
                 }
                 rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
                 roff[j] = t.off;
@@ -377,10 +353,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             // view's similarity tile is filled (round 1 walked 32 hypotheses at a time behind 4 barriers per view).
             constexpr int RPL = DT / LPI;
             const float xf = (float)xB, yf = (float)yB;
-            const float* P = a.proj + ((size_t)b * N + v) * 16;
-            const float rx = (fmaf(P[0], xf, P[1] * yf) + P[2]) * sxs, tx = P[3] * sxs;
-            const float ry = (fmaf(P[4], xf, P[5] * yf) + P[6]) * sys, ty = P[7] * sys;
-            const float rz = fmaf(P[8], xf, P[9] * yf) + P[10], tz = P[11];
+            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);
             float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
             int roff[RPL];
 #pragma unroll
@@ -390,13 +363,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
                 t.off = 0;
                 t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
                 if (okB && d < D) {
-                    const float dep = a.depth[((size_t)b * D + d) * hw + pB];
-                    const float pz = fmaf(rz, dep, tz);
-                    if (pz > 1e-3f) {  // behind-camera hypotheses sample nothing (reference sentinel, module.py:166-169)
-                        float inv = __builtin_amdgcn_rcpf(pz);
-                        inv = inv * fmaf(-pz, inv, 2.0f);
-                        t = pmn_make_taps(fmaf(rx, dep, tx) * inv, fmaf(ry, dep, ty) * inv, hs, ws);
-                    }
+                    float ix, iy;
+                    pmn_pose_position(lane_pose, a.depth[((size_t)b * D + d) * hw + pB], h, w, hs, ws, ix, iy);
+                    t = pmn_make_taps(ix, iy, hs, ws);
                 }
                 rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
                 roff[j] = t.off;

@@ -4,9 +4,10 @@
 //  * coordinate maths is compiled under `#pragma clang fp contract(off)` so hipcc does not contract it into
 //    FMAs -- the reference materialises every intermediate tensor (one rounding per op), and bit-identical
 //    sample positions make the tap sets identical to the oracle's;
-//  * divisions are IEEE (hipcc default: correctly rounded fp32 divide) -- except the perspective division of the warp in the
-//    gather kernels and the depth-weight / normalisation of pmn_aggregate_regress, which use v_rcp_f32 + one Newton step
-//    (relative error < 4e-7: positions agree with the reference's own fp32 rounding to ~1e-4 px);
+//  * divisions are IEEE (hipcc default: correctly rounded fp32 divide), including -- since round 4 -- the warp's perspective
+//    division and normalisation chain (pmn_pose_position); the exception left is the depth-weight sigmoid / normalisation of
+//    pmn_aggregate_regress (v_exp_f32, v_rcp_f32 + one Newton step, relative error < 4e-7), measured NOT to move a pixel
+//    (profiles/r04_ieee_attribution.md);
 //  * bilinear taps follow ATen's grid_sampler_2d: corner weights (x1-ix)*(y1-iy) ..., corners accumulated in
 //    the order nw, ne, sw, se, out-of-range corners contribute nothing.
 #pragma once
@@ -96,18 +97,35 @@ __device__ __forceinline__ float pmn_unnorm_noalign(float c, int size) {
     return ((c + 1.0f) * (float)size - 1.0f) / 2.0f;
 }
 
-// Homography warp of reference pixel (x,y) at depth d into the source map (reference models/module.py:161-181).
+// Homography warp of reference pixel (x,y) at depth d into the source map (reference models/module.py:161-181), in the
+// reference's own sequence of IEEE operations: rot = R [x y 1]^T, p = rot * d + t, the perspective DIVISIONS, the normalisation to
+// [-1, 1] with (size-1)/2 and grid_sample's un-normalisation.  Every kernel that warps uses these two functions since round 4:
+// rounds 1-3 took the division as v_rcp + one Newton step with the normalise / un-normalise round trip folded into one scale --
+// positions within 1e-4 px of these, and exactly that was 9 of 10 of the free-running outlier pixels against the reference's own
+// output (6.5e-4 -> 7.3e-5 of the final-depth pixels beyond 1e-3 at 1600x1200; profiles/r04_ieee_attribution.md).
 // P = relative projection src_proj @ inv(ref_proj), row-major 4x4.
-__device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, float x, float y, float d, int h,
-                                                  int w, int hs, int ws, float& ix, float& iy) {
+struct PmnPose { float rx, ry, rz, tx, ty, tz; };  // rot_xyz of one reference pixel for one view, and the translation
+
+__device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y) {
 #pragma clang fp contract(off)
-    float rx = (P[0] * x + P[1] * y) + P[2];
-    float ry = (P[4] * x + P[5] * y) + P[6];
-    float rz = (P[8] * x + P[9] * y) + P[10];
-    float px = rx * d + P[3];
-    float py = ry * d + P[7];
-    float pz = rz * d + P[11];
-    if (pz <= 1e-3f) {  // behind / on the source camera: (w, h, 1) lands outside every tap
+    PmnPose q;
+    q.rx = (P[0] * x + P[1] * y) + P[2];
+    q.ry = (P[4] * x + P[5] * y) + P[6];
+    q.rz = (P[8] * x + P[9] * y) + P[10];
+    q.tx = P[3];
+    q.ty = P[7];
+    q.tz = P[11];
+    return q;
+}
+
+// returns false for a hypothesis behind / on the source camera: (w, h, 1) then lands outside every tap (the reference's sentinel)
+__device__ __forceinline__ bool pmn_pose_position(const PmnPose& q, float d, int h, int w, int hs, int ws, float& ix, float& iy) {
+#pragma clang fp contract(off)
+    float px = q.rx * d + q.tx;
+    float py = q.ry * d + q.ty;
+    float pz = q.rz * d + q.tz;
+    const bool front = pz > 1e-3f;
+    if (!front) {
         px = (float)w;
         py = (float)h;
         pz = 1.0f;
@@ -117,6 +135,13 @@ __device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, f
     float yn = gy / ((float)(h - 1) / 2.0f) - 1.0f;
     ix = pmn_unnorm_align(xn, ws);
     iy = pmn_unnorm_align(yn, hs);
+    return front;
+}
+
+__device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, float x, float y, float d, int h,
+                                                  int w, int hs, int ws, float& ix, float& iy) {
+    const PmnPose q = pmn_make_pose(P, x, y);
+    pmn_pose_position(q, d, h, w, hs, ws, ix, iy);
 }
 
 // Neighbour k of pixel (x,y): fixed table offset + learned offset, normalised with (size-1)/2 (get_grid,

@@ -3,8 +3,8 @@
 ``PatchmatchNet(...)`` takes the reference's constructor arguments, exposes the same sub-module / state-dict names
 (``feature``, ``patchmatch_1..3``, ``upsample_net``) and ``forward`` returns the same triple.  Everything runs in the HIP
 kernels of ``patchmatchnet_amd/csrc`` -- the learned-PatchMatch cascade (no other implementation exists: no CPU / eager
-fallback) and, by default, FeatureNet and Refinement too (``hip_feature_net``: stem / Winograd / MFMA convolutions, folded FPN
-head, fused refinement).  FeatureNet and Refinement are also ordinary nn.Modules with the reference's parameters; with
+fallback) and, by default, FeatureNet and Refinement too (``hip_feature_net``: stem + split-operand fp16 matrix-core convolutions,
+folded FPN head, fused refinement; ``f16_split = False`` or a checkpoint outside float16's range: the fp32 kernels).  FeatureNet and Refinement are also ordinary nn.Modules with the reference's parameters; with
 ``hip_feature_net = False`` they run on PyTorch-ROCm / MIOpen, which is what the parity tests compare the HIP path with.
 
 INFERENCE ONLY: ``forward`` raises in training mode -- the kernels have no backward pass and the reference's train.py /
@@ -14,12 +14,14 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import warnings
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, params
+from . import _lib, ops, params
 from ._lib import PmnError
 from .module import ConvBnReLU
 from .patchmatch import PatchMatch
@@ -42,13 +44,18 @@ class FeatureNet(nn.Module):
         self.inner2 = nn.Conv2d(16, 64, 1, bias=True)
         self.output2 = nn.Conv2d(64, 32, 1, bias=False)
         self.output3 = nn.Conv2d(64, 16, 1, bias=False)
-        # forward_hip: conv2..conv10 on the FP16 matrix cores with split (hi + lo/2048) operands: fp32-convolution accuracy at 16/3
-        # the fp32 MFMA rate (csrc/conv_f16s.hip).  False = rounds 1-2's fp32 Winograd / fp32 MFMA kernels (flags below).
+        # forward_hip has ONE switch: f16_split = True (default) runs conv1..conv10 on the FP16 matrix cores with split (hi + lo/2048)
+        # operands -- fp32-convolution accuracy at 16/3 the fp32 MFMA rate (csrc/conv_f16s.hip); False = the fp32 kernels (pmn_stem +
+        # pmn_conv2d, the VALU direct convolution).  A checkpoint whose BatchNorm-folded weights leave float16's finite range
+        # (include/pmn_hip.h, "fp16-split entry points") takes the fp32 kernels too and warns once (``f16_domain_error`` says why).
         self.f16_split = True
-        self.winograd5 = True  # forward_hip: conv2, conv5, conv8 (5x5 stride 2) in phase-decomposed Winograd form
-        self.winograd = True  # forward_hip: conv3/4, conv6/7, conv9/10 in Winograd F(2x2,3x3) form (False = direct convolutions)
-        self.mfma_convs = True  # forward_hip: conv5..conv10 on the fp32 matrix cores (False = VALU kernel for every layer)
-        self.fold_fpn = True  # forward_hip: composed 1x1 convolutions (False = layer by layer, as the reference orders them)
+        self.f16_domain_error: Optional[str] = None
+        # verification switch, not a performance choice: False = the FPN head layer by layer in the reference's order instead of the
+        # host-composed 1x1 convolutions (an algebraic re-association)
+        self.fold_fpn = True
+        # research build only (PMN_EXPERIMENTAL=1, libpmn_hip_experimental.so): rounds 1-2's fp32 alternatives, read when f16_split is
+        # False -- Winograd 3x3 / 5x5-stride-2, fp32 MFMA wide layers, the VALU form of the FPN's 1/8 level.  Ignored by the product.
+        self.research = dict(winograd=False, winograd5=False, mfma_convs=False, fpn8_valu=False)
 
     # ---- HIP execution (pmn_conv2d): same parameters, channels-last activations, BN/ReLU/FPN-add fused ----------------
     _SPEC = [(3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1),
@@ -61,20 +68,26 @@ class FeatureNet(nn.Module):
         if getattr(self, "_pack_key", None) != key:
             dev = self.output1.weight.device
             pk = {}
+            f16_ok, self.f16_domain_error = True, None
             for i in range(11):
                 m = getattr(self, f"conv{i}")
                 w, s = params.pack_conv(m.conv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                         eps=m.bn.eps)
                 pk[f"conv{i}"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
                 cv = m.conv
+                if (cv.kernel_size[0], cv.stride[0], cv.in_channels, cv.out_channels) in ops.F16S_SHAPES and f16_ok:
+                    try:
+                        w, s = params.pack_conv_f16s(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
+                                                     eps=m.bn.eps)
+                        pk[f"conv{i}_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                    except params.F16DomainError as e:
+                        f16_ok, self.f16_domain_error = False, f"conv{i}: {e}"
+                if not _lib.experimental():
+                    continue
                 if (cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]) in ops.MFMA_CONV_SHAPES:
                     w, s = params.pack_conv_mfma(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
                                                  eps=m.bn.eps)
                     pk[f"conv{i}_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                if (cv.kernel_size[0], cv.stride[0], cv.in_channels, cv.out_channels) in ops.F16S_SHAPES:
-                    w, s = params.pack_conv_f16s(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
-                                                 eps=m.bn.eps)
-                    pk[f"conv{i}_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
                 if cv.kernel_size[0] == 3 and cv.stride[0] == 1 and cv.in_channels == cv.out_channels and \
                         cv.in_channels in (16, 32, 64):
                     w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
@@ -86,9 +99,17 @@ class FeatureNet(nn.Module):
                                                                      m.bn.running_var), eps=m.bn.eps)
                     pk[f"conv{i}_wino5"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             m1 = self.conv1
-            w, s = params.pack_stem_conv1_f16s(m1.conv.weight, bn=(m1.bn.weight, m1.bn.bias, m1.bn.running_mean, m1.bn.running_var),
-                                              eps=m1.bn.eps)
-            pk["conv1_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            try:
+                w, s = params.pack_stem_conv1_f16s(m1.conv.weight, bn=(m1.bn.weight, m1.bn.bias, m1.bn.running_mean, m1.bn.running_var),
+                                                  eps=m1.bn.eps)
+                pk["conv1_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            except params.F16DomainError as e:
+                f16_ok, self.f16_domain_error = False, f"conv1: {e}"
+            if not f16_ok:  # the whole network then runs the fp32 kernels: one arithmetic per forward, stated once
+                for k in [k for k in pk if k.endswith("_f16s")]:
+                    del pk[k]
+                warnings.warn("FeatureNet: " + self.f16_domain_error + " -- using the fp32 kernels (pmn_stem / pmn_conv2d) instead of "
+                              "the fp16-split matrix-core kernels", RuntimeWarning, stacklevel=2)
             for name in ("output1", "inner1", "inner2", "output2", "output3"):
                 m = getattr(self, name)
                 w, s = params.pack_conv(m.weight, bias=m.bias)
@@ -112,7 +133,7 @@ class FeatureNet(nn.Module):
         B, _, H, W = imgs[0].shape
         t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
         for i, im in enumerate(imgs):  # conv0 + conv1 fused (pmn_stem_f16s: conv1 on the fp16 matrix cores; pmn_stem: all fp32 VALU)
-            if self.f16_split:
+            if self.f16_split and "conv1_f16s" in pk:
                 ops.stem_f16s(im.contiguous(), *pk["conv0"], *pk["conv1_f16s"], out=t[i * B:(i + 1) * B])
             else:
                 ops.stem(im.contiguous(), *pk["conv0"], *pk["conv1"], out=t[i * B:(i + 1) * B])
@@ -122,13 +143,13 @@ class FeatureNet(nn.Module):
                 continue
             if self.f16_split and f"conv{i}_f16s" in pk:  # fp16 matrix cores, split operands
                 t = ops.conv2d_f16s(t, *pk[f"conv{i}_f16s"], k, s, relu=True)
-            elif self.winograd and f"conv{i}_wino" in pk:  # 3x3 stride-1 layers: Winograd F(2x2,3x3) on the matrix cores
+            elif self.research["winograd"] and f"conv{i}_wino" in pk:  # research build: Winograd F(2x2,3x3), fp32 matrix cores
                 t = ops.conv3x3_wino(t, *pk[f"conv{i}_wino"], relu=True)
-            elif self.winograd5 and f"conv{i}_wino5" in pk:  # 5x5 stride-2 layers: four parity sub-convolutions in Winograd form
+            elif self.research["winograd5"] and f"conv{i}_wino5" in pk:  # research build: 5x5 stride 2 as four Winograd sub-convolutions
                 t = ops.conv5x5s2_wino(t, *pk[f"conv{i}_wino5"], relu=True)
-            elif self.mfma_convs and f"conv{i}_mfma" in pk:  # wide layers: implicit GEMM on the matrix cores
+            elif self.research["mfma_convs"] and f"conv{i}_mfma" in pk:  # research build: fp32 implicit GEMM on the matrix cores
                 t = ops.conv2d_mfma(t, *pk[f"conv{i}_mfma"], k, s, p, relu=True)
-            else:
+            else:  # fp32 VALU direct convolution
                 w, sh = pk[f"conv{i}"]
                 t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)
             if i in (4, 7, 10):
@@ -137,10 +158,10 @@ class FeatureNet(nn.Module):
         if self.fold_fpn:
             # the FPN head is linear: its 1x1 convolutions are composed on the host (params.fold_fpn) and each level is one
             # bandwidth-bound kernel -- the 64-channel intermediates at 1/4 and 1/2 resolution never exist
-            if self.mfma_convs:  # 64 -> 112 channels: a GEMM, on the matrix cores
-                f3, u8 = ops.pointwise_split_mfma(eighth, *pk["fpn8_mfma"], cout=112, ca=64)
-            else:
+            if self.research["fpn8_valu"]:  # (test hook: the VALU form of the same level)
                 f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)
+            else:  # 64 -> 112 channels: a GEMM, on the fp32 matrix cores (pmn_conv2d_mfma's 1x1 form)
+                f3, u8 = ops.pointwise_split_mfma(eighth, *pk["fpn8_mfma"], cout=112, ca=64)
             f2, u4 = ops.fpn_level(quarter, u8, *pk["fpn4"], ca=32)
             f1, _ = ops.fpn_level(half, u4, *pk["fpn2"], ca=16)
             return {3: f3, 2: f2, 1: f1}
@@ -165,7 +186,7 @@ class FeatureNet(nn.Module):
 
 class Refinement(nn.Module):
     """Depth-residual refinement at full resolution (reference models/net.py:73-122).  ``forward`` = PyTorch-ROCm (parity
-    reference), ``forward_hip`` = pmn_conv2d at half resolution + pmn_refine_fused (default; ``one_kernel = False``: pmn_refine_front / pmn_refine_tail)."""
+    reference), ``forward_hip`` = pmn_conv2d at half resolution + pmn_refine_fused (default; ``f16_split = False``: pmn_refine_front / pmn_refine_tail)."""
 
     def __init__(self) -> None:
         super().__init__()
@@ -176,8 +197,13 @@ class Refinement(nn.Module):
         self.bn = nn.BatchNorm2d(8)
         self.conv3 = ConvBnReLU(in_channels=16, out_channels=8)
         self.res = nn.Conv2d(8, 1, kernel_size=3, padding=1, bias=False)
-        self.fused_tail = True  # forward_hip: pmn_refine_front + pmn_refine_tail (False = one launch per layer)
-        self.one_kernel = True  # ... and those two as ONE launch, conv3 on the fp16 matrix cores (pmn_refine_fused); needs fused_tail
+        # forward_hip, full-resolution half: f16_split = True (default) = ONE launch with conv3 on the fp16 matrix cores (split operands:
+        # pmn_refine_fused); False -- or conv3's folded weights outside float16's range -- = the fp32 pair pmn_refine_front +
+        # pmn_refine_tail.
+        self.f16_split = True
+        self.f16_domain_error: Optional[str] = None
+        # verification switch, not a performance choice: one pmn_conv2d / pmn_deconv3x3s2 launch per layer in the reference's order
+        self.research = dict(layers=False)
 
     def _packed(self):
         srcs = [p for p in self.parameters()] + [b for b in self.buffers() if b.dtype.is_floating_point]
@@ -199,8 +225,14 @@ class Refinement(nn.Module):
             pk["res"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             pk["tail"] = tuple(torch.from_numpy(a).to(dev) for a in params.pack_refine_tail(
                 self.conv3.conv.weight, bn_of(self.conv3.bn), self.res.weight, eps=self.conv3.bn.eps))
-            w, s = params.pack_refine_conv3_f16s(self.conv3.conv.weight, bn_of(self.conv3.bn), eps=self.conv3.bn.eps)
-            pk["conv3_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            self.f16_domain_error = None
+            try:
+                w, s = params.pack_refine_conv3_f16s(self.conv3.conv.weight, bn_of(self.conv3.bn), eps=self.conv3.bn.eps)
+                pk["conv3_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            except params.F16DomainError as e:
+                self.f16_domain_error = f"conv3: {e}"
+                warnings.warn("Refinement: " + self.f16_domain_error + " -- using the fp32 kernels (pmn_refine_front / pmn_refine_tail)",
+                              RuntimeWarning, stacklevel=2)
             self._pack, self._pack_key = pk, key
         return self._pack
 
@@ -214,8 +246,8 @@ class Refinement(nn.Module):
         d = ((depth_0 - lo) / span).contiguous()
         t = ops.conv2d(d, *pk["conv1"], 8, 3, 1, 1, relu=True, in_nchw=True)                             # [B,H/2,W/2,8]
         t = ops.conv2d(t, *pk["conv2"], 8, 3, 1, 1, relu=True)
-        if self.fused_tail and img.shape[2] % 2 == 0 and img.shape[3] % 2 == 0:
-            if self.one_kernel:  # the full-resolution half in one launch: x16 never leaves LDS
+        if not self.research["layers"]:
+            if self.f16_split and "conv3_f16s" in pk:  # the full-resolution half in one launch: x16 never leaves LDS
                 return ops.refine_fused(img.contiguous(), t, *pk["conv0"], *pk["deconv"], *pk["conv3_f16s"], pk["tail"][2], d,
                                         depth_min.float().contiguous(), depth_max.float().contiguous())
             # ... in two launches: (deconv || conv0) -> x16, then conv3 -> res -> residual + de-normalisation

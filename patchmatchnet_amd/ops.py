@@ -451,6 +451,8 @@ def conv2d_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, K: 
 def conv3x3_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """pmn_conv3x3_wino: 3x3 / stride 1 / padding 1 convolution with cin == cout in {16,32,64} + folded-BN shift + ReLU in
     Winograd F(2x2,3x3) form on the matrix cores; x [N,H,W,C] channels-last, weights from params.pack_conv_wino."""
+    if not _lib.experimental():
+        raise PmnError("conv3x3_wino: research build only (make -C patchmatchnet_amd/csrc EXPERIMENTAL=1, PMN_EXPERIMENTAL=1)")
     for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
         _dev(t_, n_)
     N, H, W, C = x.shape
@@ -466,6 +468,8 @@ def conv3x3_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, re
 def conv5x5s2_wino(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """pmn_conv5x5s2_wino: 5x5 / stride 2 / padding 2 convolution + folded-BN shift + ReLU in phase-decomposed Winograd form on
     the matrix cores; x [N,H,W,cin] channels-last, weights from params.pack_conv5x5s2_wino -> [N,(H-1)//2+1,(W-1)//2+1,cout]."""
+    if not _lib.experimental():
+        raise PmnError("conv5x5s2_wino: research build only (make -C patchmatchnet_amd/csrc EXPERIMENTAL=1, PMN_EXPERIMENTAL=1)")
     for n_, t_ in (("x", x), ("weights", weights), ("shift", shift)):
         _dev(t_, n_)
     N, H, W, cin = x.shape

@@ -231,9 +231,23 @@ def f16s_chunk(cin: int, ksize: int) -> int:
     return 16 if cin == 32 else 8
 
 
+F16_MAX = 65504.0  # largest finite float16: |x| >= F16_MAX makes hi = +-inf (include/pmn_hip.h, "fp16-split entry points")
+
+
+class F16DomainError(ValueError):
+    """A (BatchNorm-folded) weight lies outside float16's finite range: the fp16-split kernels cannot represent it; the modules
+    fall back to the fp32 kernels for the whole network and say so (net.FeatureNet / net.Refinement / patchmatch.PatchMatch)."""
+
+
 def split_f16(x: np.ndarray):
-    """float -> (hi, lo) float16 pair with x ~= hi + lo / F16S_LO_SCALE (relative error 2^-22)."""
-    x32 = np.asarray(x, np.float64).astype(np.float32)
+    """float -> (hi, lo) float16 pair with x ~= hi + lo / F16S_LO_SCALE (relative error 2^-22 for 6.1e-5 <= |x| < 65504; smaller
+    magnitudes keep an ABSOLUTE error <= 3e-8).  Raises F16DomainError for |x| >= 65504 or a non-finite value: a tiny BatchNorm
+    running_var can fold into such a scale, and the kernels themselves do not check (hi = inf, lo = NaN, and the zero-weight padding
+    k-blocks turn 0 * inf into NaN everywhere)."""
+    x64 = np.asarray(x, np.float64)
+    if x64.size and not (np.isfinite(x64).all() and float(np.abs(x64).max()) < F16_MAX):
+        raise F16DomainError(f"weight magnitude {float(np.nanmax(np.abs(x64))):.3e} outside float16's finite range (< {F16_MAX})")
+    x32 = x64.astype(np.float32)
     hi = x32.astype(np.float16)
     lo = ((x32 - hi.astype(np.float32)) * np.float32(F16S_LO_SCALE)).astype(np.float16)
     return hi, lo

@@ -21,7 +21,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, params
+import warnings
+
+from . import _lib, ops, params
 from ._lib import PmnError
 from .module import ConvBnReLU3D, is_empty
 
@@ -232,11 +234,15 @@ class PatchMatch(nn.Module):
         nn.init.constant_(self.eval_conv.bias, 0.0)
         self.feature_weight_net = FeatureWeightNet(evaluate_neighbors, self.G)
 
-        # offset heads through pmn_conv2d (True) or MIOpen (False)
+        # offset heads in HIP (True) or on MIOpen (False: what the parity tests compare with)
         self.hip_offset_heads = True
-        self.mfma_offset_heads = True  # ... and on the matrix cores (pmn_conv2d_mfma, both heads in one launch) when supported
-        self.f16_split_heads = True  # ... on the FP16 matrix cores with split operands (pmn_offset_heads_f16s) for the reference's
-        #                              three (channels, dilation) combinations; fp32-convolution accuracy (csrc/conv_f16s.hip)
+        # ONE switch for the HIP form: f16_split = True (default) = both heads of the stage as one dilated convolution on the FP16 matrix
+        # cores with split operands (pmn_offset_heads_f16s: fp32-convolution accuracy, csrc/conv_f16s.hip) wherever the kernel covers the
+        # shape -- the reference's three (channels, dilation) pairs with the row count padded to 32, 48 or 64 -- and the heads' weights
+        # fit float16's range; otherwise, and with False, pmn_conv2d (fp32 VALU), one launch per head.
+        self.f16_split = True
+        self.f16_domain_error: Optional[str] = None
+        self.research = dict(mfma_offset_heads=False)  # research build only (PMN_EXPERIMENTAL=1): round 2's fp32 MFMA planar form
         self._heads = None
         self._heads_key = None
         self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
@@ -252,16 +258,25 @@ class PatchMatch(nn.Module):
                 w, s = params.pack_conv(m.weight, bias=m.bias)
                 pk[name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             # matrix-core form: both heads as ONE convolution (propa rows, then eval rows), with and without the propa rows
-            if (self.eval_conv.in_channels, self.dilation) in ops.MFMA_HEAD_SHAPES:
-                for name, mods in (("both", (self.propa_conv, self.eval_conv)), ("eval_only", (self.eval_conv,))):
-                    wcat = torch.cat([m.weight.detach() for m in mods], 0)
-                    bcat = torch.cat([m.bias.detach() for m in mods], 0)
-                    if wcat.shape[0] <= 64:
-                        w, s = params.pack_conv_mfma(wcat, bias=bcat)
-                        pk["mfma_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                        if (self.eval_conv.in_channels, self.dilation) in ops.F16S_HEAD_SHAPES:
-                            w, s = params.pack_offset_heads_f16s(wcat, bcat)
-                            pk["f16s_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            self.f16_domain_error = None
+            for name, mods in (("both", (self.propa_conv, self.eval_conv)), ("eval_only", (self.eval_conv,))):
+                wcat = torch.cat([m.weight.detach() for m in mods], 0)
+                bcat = torch.cat([m.bias.detach() for m in mods], 0)
+                rows = wcat.shape[0]
+                # pmn_offset_heads_f16s instantiates padded row counts 32, 48 and 64 (16 -- e.g. no propagation and <= 8 evaluation
+                # neighbours -- is not one of them: those configurations take pmn_conv2d)
+                if (self.eval_conv.in_channels, self.dilation) in ops.F16S_HEAD_SHAPES and (rows + 15) // 16 * 16 in (32, 48, 64):
+                    try:
+                        w, s = params.pack_offset_heads_f16s(wcat, bcat)
+                        pk["f16s_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+                    except params.F16DomainError as e:
+                        self.f16_domain_error = f"offset heads: {e}"
+                if _lib.experimental() and (self.eval_conv.in_channels, self.dilation) in ops.MFMA_HEAD_SHAPES and rows <= 64:
+                    w, s = params.pack_conv_mfma(wcat, bias=bcat)
+                    pk["mfma_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
+            if self.f16_domain_error is not None:
+                warnings.warn(f"PatchMatch stage {self.stage}: " + self.f16_domain_error + " -- using pmn_conv2d (fp32)", RuntimeWarning,
+                              stacklevel=2)
             self._heads, self._heads_key = pk, key
         return self._heads
 
@@ -294,11 +309,11 @@ class PatchMatch(nn.Module):
             pk = self._packed_heads()
             key = "mfma_both" if propagate_any else "mfma_eval_only"
             fkey = "f16s_both" if propagate_any else "f16s_eval_only"
-            if self.f16_split_heads and fkey in pk:  # fp16 matrix cores, split operands (round 3)
+            if self.f16_split and fkey in pk:  # fp16 matrix cores, split operands (round 3)
                 n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
                 a_, b_ = ops.offset_heads_f16s(ref_nhwc, *pk[fkey], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
                 propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)
-            elif self.mfma_offset_heads and key in pk:
+            elif self.research["mfma_offset_heads"] and key in pk:  # research build
                 n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
                 a_, b_ = ops.offset_heads_mfma(ref_nhwc, *pk[key], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
                 propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)

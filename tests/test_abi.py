@@ -258,3 +258,29 @@ def test_pack_conv5x5s2_wino_reproduces_the_stride2_convolution():
     ref = np.array([[[(d[2 * a:2 * a + 5, 2 * b:2 * b + 5].transpose(2, 0, 1) * w[k]).sum() for k in range(32)] for b in range(2)]
                     for a in range(2)])
     np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def _integration_stub():
+    """The first ```python block of INTEGRATION.md (the binding a reference maintainer is told to paste), pointed at the built library."""
+    from patchmatchnet_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# --- binding.*?)```", text, flags=re.S)
+    assert m, "INTEGRATION.md lost its binding block"
+    code = m.group(1)
+    assert '"libpmn_hip.so"' in code
+    return code.replace('"libpmn_hip.so"', repr(_lib.LIB_PATH))
+
+
+def test_integration_stub_executes():
+    """INTEGRATION.md's ctypes binding runs against the library as built: every symbol it names exists with that arity, and the ABI
+    version it asserts is the header's (round 3 shipped a stub that asserted 11 against a library at 16)."""
+    from patchmatchnet_amd import _lib
+    _lib.lib()
+    ns = {}
+    exec(compile(_integration_stub(), "INTEGRATION.md", "exec"), ns)
+    assert ns["_L"].pmn_abi_version() == _lib.ABI_VERSION
+    hdr = open(HEADER).read()
+    assert f"#define PMN_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+    # the argument counts the stub declares are the header's
+    for name in ("pmn_warp_correlate", "pmn_aggregate_regress", "pmn_differentiable_warping"):
+        assert len(getattr(ns["_L"], name).argtypes) == len(_lib.SIGNATURES[name]), name

@@ -86,9 +86,11 @@ def _index_check(got_idx, got_score, want_idx):
     return frac
 
 
-@pytest.mark.parametrize("scene,H,W,nsrc", [("surface", 1200, 1600, 5), ("rolled", 1200, 1600, 5), ("surface", 1056, 1920, 7)])
+@pytest.mark.parametrize("scene,H,W,nsrc", [("surface", 1200, 1600, 5), ("rolled", 1200, 1600, 5), ("surface", 1056, 1920, 7),
+                                            ("surface", 2048, 3072, 10)])
 def test_chained_cascade_from_hip_featurenet(scene, H, W, nsrc):
-    """bench.py's samples (cfg-2 on both scenes; cfg-3 = 1920x1056, N=7): HIP FeatureNet features -> the whole HIP cascade vs
+    """bench.py's samples (cfg-2 on both scenes; cfg-3 = 1920x1056, N=7; since round 4 cfg-5 = 3072x2048, N=10: the whole forward's
+    VALUES at the largest BASELINE configuration, not only their ranges): HIP FeatureNet features -> the whole HIP cascade vs
     oracle.cascade-style chaining on the same features."""
     P = _gpu()
     import bench
@@ -181,9 +183,11 @@ def test_cfg2_scene_end_to_end_against_the_reference_itself():
     Gates.  The reference does not reproduce ITSELF to 1e-3 on every pixel: profiles/r03_noise_floor.json (scripts/noise_floor.py)
     has, on this scene, 4.6e-5 of the final-depth pixels beyond 1e-3 between 8 and 1 threads and 2.3e-4 between oneDNN and native
     convolutions (max 4.6e-3 / 9.1e-3; p99 2e-7), because a rounding-level change of a feature occasionally moves the soft arg-max
-    of one pixel to a neighbouring hypothesis and later stages keep it.  So: the BULK must agree far inside the north star's 1e-3
-    (p99 <= 1e-5), and the exceptional pixels must be no more frequent than a small multiple of the reference's own floor
-    (<= 1e-3 of the pixels beyond 1e-3, none beyond 5e-2)."""
+    of one pixel to a neighbouring hypothesis and later stages keep it.  Round 4 attributed this engine's excess over that floor
+    (6.5e-4 of the pixels, max 1.9e-2 in round 3) to the warp's approximate perspective division and removed it
+    (profiles/r04_ieee_attribution.md): measured now 7.3e-5 of the final-depth pixels beyond 1e-3, max 5.5e-3, depth_index mismatch
+    1.5e-4 -- INSIDE the reference's own floor.  The gates sit at 1.5x those measurements (the computation is deterministic: same
+    kernels, same inputs, same bits on every box), the bulk far inside the north star's 1e-3 (p99 <= 1e-5)."""
     P = _gpu()
     model, params, kw = _model(P)
     g = GU.load_npz("cfg2_scene.npz")
@@ -225,11 +229,11 @@ def test_cfg2_scene_end_to_end_against_the_reference_itself():
     assert rep["view_weights_abs_max"] < 1e-4, rep["view_weights_abs_max"]
     for k in ("s3_it2", "s2_it1", "s2_it2", "s1_it1", "final"):
         assert rep[k]["p99"] < 1e-5, (k, rep[k])
-        assert rep[k]["frac_over_1e-3"] < 1e-3, (k, rep[k])
-        assert rep[k]["max"] < 5e-2, (k, rep[k])
-    assert fin["p999"] < 1e-3, fin
+        assert rep[k]["frac_over_1e-3"] < 1.15e-4, (k, rep[k])  # measured 0 / 0 / 5.0e-5 / 7.5e-5 / 7.3e-5 (round 3: up to 6.5e-4)
+        assert rep[k]["max"] < 8.5e-3, (k, rep[k])              # measured <= 5.5e-3 (round 3: 2.2e-2)
+    assert fin["p999"] < 1.5e-4, fin                            # measured 9.7e-5 (round 3: 5.5e-4)
     assert rep["vs_ground_truth_mm"]["median"] < 1.0, rep["vs_ground_truth_mm"]  # the reference itself: 0.63 mm
-    assert rep["depth_index_mismatch_frac"] < 2e-3 and rep["confidence_frac_over_1e-3"] < 5e-3, rep
+    assert rep["depth_index_mismatch_frac"] < 2.2e-4 and rep["confidence_frac_over_1e-3"] < 2.7e-3, rep  # measured 1.5e-4 / 1.8e-3
 
 
 @pytest.mark.parametrize("stage,n_src,H,W", [(3, 7, 1056, 1920), (2, 7, 1056, 1920), (1, 7, 1056, 1920),
@@ -292,12 +296,13 @@ def test_fullsize_stage_against_oracle_cfg3_cfg5(stage, n_src, H, W):
             if stage == 3:
                 # (the weights first: _argmax_check's tie criterion is stated in terms of them)
                 worst["view_weights_abs_max"] = GU.abs_err(n(rec["view_weights"]), orec["view_weights"])
-                # cfg-5's synthetic rig reaches 0.8 rad between reference and source view: grazing projections, where the
-                # 1e-4 px position noise of fp32 meets steep feature gradients -- measured 2.3e-4 there, <= 2e-5 elsewhere
-                assert worst["view_weights_abs_max"] < (1e-4 if n_src <= 7 else 5e-4)
+                # cfg-5's synthetic rig reaches 0.8 rad between reference and source view: grazing projections with steep (random)
+                # feature gradients -- measured 1.0e-4 there since the warp uses the reference's IEEE chain (round 3: 2.3e-4 with
+                # the approximate perspective division, tolerance 5e-4), <= 2e-5 elsewhere
+                assert worst["view_weights_abs_max"] < (1e-4 if n_src <= 7 else 2e-4)
                 worst["view_weight_argmax_mismatch_frac"] = _argmax_check(
                     n(rec["view_weight_argmax"]), n(rec["view_weights"]), orec["view_weight_argmax"], orec["view_weights"],
-                    tie=1e-4 if n_src <= 7 else 5e-4)
+                    tie=1e-4 if n_src <= 7 else 2e-4)
         rel = np.abs(n(rec["depth"]) - orec["depth"]) / orec["depth"]
         worst[f"it{it + 1}_depth_rel_max"] = float(rel.max())
         assert rel.max() < 1e-3, (it, float(rel.max()))

@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _research():
+    """Rounds 1-2's fp32 alternatives live in the research build since round 4 (ABI 17): opt in with PMN_EXPERIMENTAL=1."""
+    from patchmatchnet_amd import _lib
+    if not _lib.experimental():
+        pytest.skip("research build only: PMN_EXPERIMENTAL=1 (+ make -C patchmatchnet_amd/csrc EXPERIMENTAL=1)")
+
+
 def _gpu():
     # fail loudly (never skip) when selected with -m gpu on a box without a usable GPU / library
     assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
@@ -288,6 +295,7 @@ def test_conv2d_against_torch(cin, cout, K, stride, pad, dil, in_nchw, out_nchw,
 def test_conv2d_mfma_against_torch(cin, cout, K, stride, H, W):
     """pmn_conv2d_mfma (fp32 implicit GEMM on the matrix cores) vs F.conv2d + BatchNorm + ReLU in float64, and vs the VALU
     kernel pmn_conv2d on the same input; ragged tiles and borders."""
+    _research()
     P = _gpu()
     from patchmatchnet_amd import params as PP
     gen = torch.Generator().manual_seed(cin * 100 + cout + H)
@@ -317,6 +325,7 @@ def test_conv2d_mfma_against_torch(cin, cout, K, stride, H, W):
 def test_offset_heads_mfma_against_torch(cin, dil, n_p, n_e, H, W, N):
     """pmn_conv2d_mfma planar form: propa_conv + eval_conv of a stage as one dilated 3x3 convolution on the matrix cores vs
     F.conv2d (float64) per head, ragged tiles, batch > 1, padded channel blocks."""
+    _research()
     P = _gpu()
     from patchmatchnet_amd import params as PP
     gen = torch.Generator().manual_seed(cin + dil + n_p + H)
@@ -365,6 +374,7 @@ def test_offset_heads_f16_split_against_torch(cin, dil, n_p, n_e, H, W, N):
 def test_conv3x3_winograd_against_torch(C, H, W):
     """pmn_conv3x3_wino (Winograd F(2x2,3x3) on the matrix cores) vs F.conv2d + BatchNorm + ReLU in float64 and vs the direct
     kernel pmn_conv2d; odd sizes (partial tiles, borders), batch 2."""
+    _research()
     P = _gpu()
     from patchmatchnet_amd import params as PP
     gen = torch.Generator().manual_seed(C + H)
@@ -391,6 +401,7 @@ def test_conv3x3_winograd_against_torch(C, H, W):
 def test_conv5x5s2_winograd_against_torch(cin, cout, H, W):
     """pmn_conv5x5s2_wino (four parity sub-convolutions in Winograd form on the matrix cores) vs F.conv2d(stride 2, padding 2) +
     BatchNorm + ReLU in float64 and vs the direct kernels; odd sizes (partial tiles, borders), batch 2."""
+    _research()
     P = _gpu()
     from patchmatchnet_amd import params as PP
     gen = torch.Generator().manual_seed(cin + H)
@@ -488,17 +499,19 @@ def test_fpn_level8_matrix_core_form_matches_valu_form():
         assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("fold", [True, False])
-def test_featurenet_hip_matches_miopen(fold):
-    """FeatureNet through pmn_conv2d vs the same module on PyTorch-ROCm (MIOpen): all three pyramid levels, with the FPN
-    head's 1x1 convolutions composed (pmn_fpn_level, the default) and layer by layer."""
+@pytest.mark.parametrize("mode", ["default", "fp32", "fp32_unfolded_fpn", "research_fp32"])
+def test_featurenet_hip_matches_miopen(mode):
+    """FeatureNet through the HIP kernels vs the same module on PyTorch-ROCm (MIOpen), all three pyramid levels: the default
+    (fp16-split matrix-core convolutions, composed FPN head), the fp32 kernels (f16_split = False: pmn_stem + pmn_conv2d), those with
+    the FPN head layer by layer in the reference's order, and -- research build only -- rounds 1-2's Winograd / fp32 MFMA kernels."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
-    model.feature.fold_fpn = fold
-    model.feature.mfma_convs = fold
-    model.feature.winograd = fold
-    model.feature.winograd5 = fold
+    model.feature.f16_split = mode == "default"
+    model.feature.fold_fpn = mode != "fp32_unfolded_fpn"
+    if mode == "research_fp32":
+        _research()
+        model.feature.research.update(winograd=True, winograd5=True, mfma_convs=True, fpn8_valu=True)
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
@@ -534,15 +547,16 @@ def test_stage_projections_kernel():
 @pytest.mark.parametrize("mode", ["one_kernel", "two_kernels", "layers"])
 @pytest.mark.parametrize("B,H,W", [(1, 96, 128), (2, 50, 70), (1, 38, 52)])
 def test_refinement_hip_matches_miopen(mode, B, H, W):
-    """Refinement through pmn_refine_fused (one launch, conv3 on the fp16 matrix cores with split operands: the default),
-    pmn_refine_front / pmn_refine_tail (two launches) or pmn_conv2d / pmn_deconv3x3s2 (layer by layer) vs the same module on
-    PyTorch-ROCm (MIOpen); ragged tiles, W % 4 != 0 (the scalar staging path) and batch > 1 included.  The one-launch form must
-    agree with the two-launch form far inside the tolerance: they differ by conv3's split-fp16 rounding only."""
+    """Refinement through pmn_refine_fused (one launch, conv3 on the fp16 matrix cores with split operands: the default) or
+    pmn_refine_front / pmn_refine_tail (f16_split = False: two fp32 launches) or one pmn_conv2d / pmn_deconv3x3s2 launch per layer
+    in the reference's order (the verification switch research["layers"]) vs the same module on PyTorch-ROCm (MIOpen); ragged tiles,
+    W % 4 != 0 (the scalar staging path) and batch > 1 included.  The one-launch form must agree with the two-launch form far
+    inside the tolerance: they differ by conv3's split-fp16 rounding only."""
     P = _gpu()
     g, params, kw = GU.load_case("default")
     model = _model(P, params, kw)
-    model.upsample_net.fused_tail = mode != "layers"
-    model.upsample_net.one_kernel = mode == "one_kernel"
+    model.upsample_net.f16_split = mode == "one_kernel"
+    model.upsample_net.research["layers"] = mode == "layers"
     gen = torch.Generator().manual_seed(5 + H)
     img = torch.rand(B, 3, H, W, generator=gen).to(DEV)
     d0 = (425.0 + 510.0 * torch.rand(B, 1, H // 2, W // 2, generator=gen)).to(DEV)
@@ -551,7 +565,7 @@ def test_refinement_hip_matches_miopen(mode, B, H, W):
         ref = model.upsample_net(img, d0, dmin, dmax)
         got = model.upsample_net.forward_hip(img, d0, dmin, dmax)
         if mode == "one_kernel":
-            model.upsample_net.one_kernel = False
+            model.upsample_net.f16_split = False
             two = model.upsample_net.forward_hip(img, d0, dmin, dmax)
             assert float(((got - two).abs() / two.abs()).max()) < 2e-6
     assert got.shape == ref.shape
@@ -836,3 +850,105 @@ def test_forward_with_images_of_different_sizes_against_the_reference():
     rel = np.abs(n(depth) - g["depth"]) / g["depth"]
     assert float(np.quantile(rel, 0.999)) < 1e-3, float(np.quantile(rel, 0.999))
     assert float((np.abs(n(conf) - g["confidence"]) > 1e-3).mean()) < 1e-2
+
+
+# ---- round 4: the fp16-split kernels' accepted range, and the configurations they do not cover ------------------------------
+
+def test_f16_split_domain():
+    """include/pmn_hip.h, "fp16-split entry points": what pmn_conv2d_f16s does at both ends of float16's range.
+      * activations of 6e4 (just inside): still the error of an fp32 convolution;
+      * activations of 1e-7 (below fp16's normal range) next to weights of normal size: ABSOLUTE error far below the output's
+        own scale (the subnormal hi keeps ~3e-8 absolute precision per factor);
+      * activations of 7e4 (outside): hi = inf -- the output is non-finite where the fp32 kernel is finite.  Documented, not
+        guarded in the kernel; weights outside the range are refused when they are packed (next test)."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(3)
+    cin = cout = 16
+    wt = 0.2 * torch.randn(cout, cin, 3, 3, generator=gen)
+    w, sh = PP.pack_conv_f16s(wt)
+    w2, s2 = PP.pack_conv(wt)
+    wd, sd, w2d, s2d = (torch.from_numpy(a).to(DEV) for a in (w, sh, w2, s2))
+    base = torch.randn(1, 20, 24, cin, generator=gen)
+    for scale, expect_finite in ((6.0e4 / 4.5, True), (1.0e-7, True), (7.0e4, False)):
+        x = (base * scale if expect_finite else torch.full_like(base, scale)).to(DEV)
+        got = P.ops.conv2d_f16s(x, wd, sd, 3, 1, relu=False)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double(), None, 1, 1).permute(0, 2, 3, 1)
+        fp32 = P.ops.conv2d(x, w2d, s2d, cout, 3, 1, 1, relu=False)
+        assert bool(torch.isfinite(fp32).all())
+        if expect_finite:
+            assert bool(torch.isfinite(got).all()), scale
+            err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err < (2e-6 if scale > 1 else 2e-3), (scale, err)  # 1e-7: relative to an output of ~1e-7 the 3e-8-level
+            #                                                            absolute error of the subnormal hi parts shows
+            assert float((got.double().cpu() - ref).abs().max()) < max(1e-6 * float(ref.abs().max()), 1e-9)
+        else:
+            assert not bool(torch.isfinite(got).all())  # hi = fp16(7e4) = inf
+
+
+def test_f16_split_weights_outside_the_range_fall_back_to_fp32():
+    """A BatchNorm running_var small enough to fold conv3's weights beyond 65504: params refuses to pack them, FeatureNet says so
+    (RuntimeWarning + f16_domain_error) and runs the fp32 kernels -- finite output equal to the MIOpen module's."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    with pytest.raises(PP.F16DomainError):
+        PP.split_f16(np.array([1.0, 7.0e4]))
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    with torch.no_grad():
+        model.feature.conv3.bn.running_var.fill_(1e-12)  # scale = gamma / sqrt(var + eps) with eps 1e-5 ... and a huge gamma
+        model.feature.conv3.bn.weight.fill_(3.0e5)
+        model.feature.conv3.bn.bias.zero_()
+    x = t(g["image_0"])
+    with pytest.warns(RuntimeWarning, match="fp32 kernels"):
+        got = model.feature.forward_hip(x)
+    assert model.feature.f16_domain_error is not None and "conv3" in model.feature.f16_domain_error
+    with torch.no_grad():
+        ref = model.feature(x)
+    for s_ in (1, 2, 3):
+        a, b = got[s_].permute(0, 3, 1, 2), ref[s_]
+        assert bool(torch.isfinite(a).all())
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-4, s_
+
+
+@pytest.mark.parametrize("n_p,n_e", [(16, 17), (4, 9)])
+def test_offset_heads_outside_the_f16_split_instantiations(n_p, n_e):
+    """pmn_offset_heads_f16s instantiates padded row counts 32, 48 and 64.  16 propagation + 17 evaluation neighbours give 66 rows
+    (80 padded): PatchMatch must not pack / call it for that stage and take pmn_conv2d instead (round 3 packed anything up to 64 rows
+    and would have handed a 16-row padding to the kernel: PMN_ERR_SHAPE); 4 + 9 = 26 rows pads to 32 and stays on the matrix cores.
+    Either way the whole forward must agree with the MIOpen heads."""
+    P = _gpu()
+    kw = dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2], patchmatch_iteration=[1, 2, 2],
+              patchmatch_num_sample=[8, 8, 16], propagate_neighbors=[0, n_p, n_p], evaluate_neighbors=[n_e, n_e, n_e])
+    torch.manual_seed(0)
+    model = P.PatchmatchNet(**kw).to(DEV).eval()
+    with torch.no_grad():
+        for pmx in (model.patchmatch_1, model.patchmatch_2, model.patchmatch_3):  # non-trivial heads (the reference initialises them to 0)
+            for m in (pmx.propa_conv, pmx.eval_conv):
+                m.weight.normal_(0, 0.02)
+                m.bias.normal_(0, 0.1)
+    imgs, K, E, dmin, dmax = _rand_sample(3, 64, 96)
+    noise = torch.rand(1, 48, 8, 12, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        d1, c1, _ = model(list(imgs), K.clone(), E, dmin, dmax, noise=noise)
+        for pmx in (model.patchmatch_2, model.patchmatch_3):
+            pk = pmx._packed_heads()
+            assert ("f16s_both" in pk) == (2 * (n_p + n_e) <= 64), sorted(pk)
+        for pmx in (model.patchmatch_1, model.patchmatch_2, model.patchmatch_3):
+            pmx.hip_offset_heads = False
+        d2, c2, _ = model(list(imgs), K.clone(), E, dmin, dmax, noise=noise)
+    assert bool(torch.isfinite(d1).all())
+    rel = ((d1 - d2).abs() / d2.abs()).flatten()
+    assert float(rel.median()) < 1e-5 and float((rel > 1e-3).float().mean()) < 2e-2
+
+
+def test_integration_stub_warps_like_the_op():
+    """INTEGRATION.md's ctypes stub of differentiable_warping, executed as written, against the golden known answer."""
+    P = _gpu()
+    import test_abi
+    ns = {}
+    exec(compile(test_abi._integration_stub(), "INTEGRATION.md", "exec"), ns)
+    g = GU.load_npz("ops_small.npz")
+    got = ns["differentiable_warping"](t(g["A_src"]), t(g["A_src_proj"]), t(g["A_ref_proj"]), t(g["A_depth"]))
+    torch.cuda.synchronize()
+    assert GU.abs_err(n(got), g["A_warped"]) < 5e-5
