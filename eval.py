@@ -60,6 +60,9 @@ def load_model(args, device):
     return model.to(device).eval()
 
 
+_DISCARD_MAPS = os.environ.get("PMN_EVAL_DISCARD_MAPS", "") == "1"  # scripts/eval_bench.py: time the pipeline without the map files
+
+
 class MapWriter:
     """Finished (depth, confidence) maps leave the device asynchronously: the [2,H,W] tensor is copied into a pinned host
     buffer on a side stream (ordered after the producing kernels by an event) and a writer thread saves the two files once
@@ -104,6 +107,8 @@ class MapWriter:
             try:
                 done.synchronize()
                 for path, arr in ((depth_path, buf[0]), (conf_path, buf[1])):
+                    if _DISCARD_MAPS:  # measurement aid (scripts/eval_bench.py --discard): everything but the file system
+                        continue
                     os.makedirs(os.path.dirname(path), exist_ok=True)
                     save_map(path, arr.numpy(), rows_flipped=flipped)
             finally:
@@ -420,9 +425,20 @@ def save_depth(args, rank, world, device, on_scan_done=None):
         refs = {dataset.metas[i][2] for i in indices}
         pyramids, images = {}, {}
         dataset.load_images = False
-        loader = DataLoader(torch.utils.data.Subset(dataset, indices), batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+
+        def samples():
+            """What DataLoader(batch_size=1, num_workers=0) would yield for these indices, without its per-sample collate machinery
+            (0.3 ms of the launch thread per sample at 300 samples/s): the camera tensors with a batch dimension, the rest as lists."""
+            for i in indices:
+                s = dataset[i]
+                yield {"intrinsics": torch.from_numpy(s["intrinsics"])[None], "extrinsics": torch.from_numpy(s["extrinsics"])[None],
+                       "depth_min": torch.tensor([s["depth_min"]], dtype=torch.float64),
+                       "depth_max": torch.tensor([s["depth_max"]], dtype=torch.float64), "ref_view": torch.tensor([s["ref_view"]]),
+                       "view_ids": torch.from_numpy(s["view_ids"])[None], "scan": [s["scan"]], "light": [s["light"]],
+                       "filename": [s["filename"]]}
+
         t_group, n_enc = time.time(), 0
-        for k, sample in enumerate(loader):
+        for k, sample in enumerate(samples()):
             start = time.time()
             ids = [int(v) for v in sample["view_ids"][0]]
             while any(v not in pyramids for v in ids):  # decode stream order = first-use order: the next views are these
@@ -712,6 +728,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise P.PmnError("eval.py needs a ROCm GPU: the learned-PatchMatch path has no CPU fallback")
     rank, world, device = pdist.init_from_env("cuda")
+    print("rank %d: %s" % (rank, pdist.bind_to_device_node(device)))  # before any pool / pinned buffer exists
 
     share = max((os.cpu_count() or 4) // max(world, 1), 1)  # this rank's share of the host's hardware threads
     if args.num_workers < 0:  # DataLoader worker PROCESSES (plain path): each forks a process with a GPU context -- keep them few

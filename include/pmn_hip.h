@@ -100,6 +100,17 @@ int pmn_warp_correlate(const float *ref_nhwc, const float *src_nhwc, const float
                        int G, int D, int h, int w, int hs, int ws, float *cost_out, float *view_weights_out,
                        int *vw_argmax_out, float *similarity_out, void *stream);
 
+/* The same, with the source views handed over as a DEVICE table of N addresses (64-bit each) of per-view [B,hs,ws,C] channels-last maps
+ * instead of one stacked [N,B,hs,ws,C] tensor: the maps stay where their producer left them.  eval.py's per-scan feature cache uses it
+ * (every view's pyramid is encoded once and read by ~num_views samples; stacking would copy 0.5 GB per 1600x1200 sample), the table
+ * itself is a static device buffer a HIP graph can keep reading while the host rewrites it between replays.  Reference: the list
+ * `src_features` of models/patchmatch.py:179-191 -- a list of separately allocated tensors there too. */
+int pmn_warp_correlate_views(const float *ref_nhwc, const void *src_view_table, const float *rel_proj,
+                             const float *depth_sample, const float *view_weights_in, int vw_shift,
+                             const float *similarity_mlp, const float *pixelwise_mlp, int B, int N, int C,
+                             int G, int D, int h, int w, int hs, int ws, float *cost_out, float *view_weights_out,
+                             int *vw_argmax_out, float *similarity_out, void *stream);
+
 /* Adaptive spatial cost aggregation + softmax + regression: depth_weight (reference models/patchmatch.py:650-669),
  * weight normalisation (:509-510), SimilarityNet's neighbour gather and weighted sum (:569-577),
  * exp(log_softmax) (:221) and depth regression (:226-237).

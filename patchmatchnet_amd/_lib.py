@@ -35,6 +35,8 @@ SIGNATURES = {
     "pmn_init_hypotheses": [_fp, _fp, _i, _fp, _fp, _i, _f, _fp, _hp, _i, _i, _i, _i, _fp, _fp, _s],
     "pmn_warp_correlate": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _ip,
                            _fp, _s],
+    "pmn_warp_correlate_views": [_fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _ip,
+                                 _fp, _s],
     "pmn_aggregate_regress": [_fp, _fp, _fp, _fp, _fp, _hp, _i, _f, _i, _i, _i, _i, _i, _fp, _fp, _s],
     "pmn_confidence": [_fp, _i, _i, _i, _i, _i, _i, _fp, _ip, _s],
     "pmn_conv2d": [_fp, _fp, _fp, _fp, _fp] + [_i] * 14 + [_s],

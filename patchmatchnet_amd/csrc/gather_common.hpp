@@ -12,7 +12,8 @@ enum { MODE_VIEWS = 0, MODE_PIXELWISE = 1, MODE_NEIGHBOR = 2 };
 
 struct GatherArgs {
     const float* ref;      // [B,h,w,C]
-    const float* src;      // [N,B,hs,ws,C]
+    const float* src;      // [N,B,hs,ws,C]  (stacked source views), or
+    const unsigned long long* src_tab;  // DEVICE table of N addresses of [B,hs,ws,C] maps (pmn_warp_correlate_views); src then null
     const float* proj;     // [B,N,4,4]
     const float* depth;    // [B,D,h,w]
     const float* offsets;  // [B,2K,h,w]   (MODE_NEIGHBOR)

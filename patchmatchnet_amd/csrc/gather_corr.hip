@@ -50,6 +50,15 @@ __device__ __forceinline__ float group_bcast_f(float v) {
     return __int_as_float(group_bcast_i<LPI, SL>(__float_as_int(v)));
 }
 
+// Source map of view v, batch element b: a slice of the stacked [N,B,hs,ws,C] tensor, or -- pmn_warp_correlate_views -- the v-th
+// entry of a device table of per-view addresses (the maps then stay where their producer left them: eval.py's per-scan feature
+// cache hands a sample its views without copying 0.5 GB of pyramids into a stacked buffer).  Wave-uniform.
+template <int C>
+__device__ __forceinline__ const char* pmn_view_base(const GatherArgs& a, int v, int b, int hs, int ws) {
+    if (a.src_tab) return reinterpret_cast<const char*>(a.src_tab[v]) + ((size_t)b * hs * ws) * (C * 4);
+    return reinterpret_cast<const char*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * (C * 4);
+}
+
 // One (pixel, hypothesis) item of the lane role: returns this lane's group-correlation value (valid in the owner lane
 // of each group; with 8-channel groups both lanes of the pair hold it).
 
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
                 rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
                 roff[j] = t.off;
             }
-            const char* sbase = reinterpret_cast<const char*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * (C * 4);
+            const char* sbase = pmn_view_base<C>(a, v, b, hs, ws);
             const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
             const float vw = okB ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
             // Batches of NB items: records broadcast + all 4*NB corner loads issued, THEN the NB blends; the fences keep hipcc
@@ -342,10 +351,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
         if (MODE == MODE_PIXELWISE && tid < NPIX) vwkey[tid] = 0ull;
         Pose pose = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (MODE != MODE_NEIGHBOR) pose = make_pose(a.proj + ((size_t)b * N + v) * 16);
-        const float4* srcv = reinterpret_cast<const float4*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
-                             ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * LPI + lc;
-        const char* sbase = reinterpret_cast<const char*>(MODE == MODE_NEIGHBOR ? a.ref : a.src) +
-                            ((size_t)(MODE == MODE_NEIGHBOR ? b : v * a.B + b) * hs * ws) * (C * 4);
+        const char* sbase = MODE == MODE_NEIGHBOR ? reinterpret_cast<const char*>(a.ref) + ((size_t)b * hs * ws) * (C * 4)
+                                                  : pmn_view_base<C>(a, v, b, hs, ws);
+        const float4* srcv = reinterpret_cast<const float4*>(sbase) + lc;
         const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
         if constexpr (MODE == MODE_PIXELWISE) {
             // Lane role as in MODE_VIEWS: every lane projects RPL hypotheses of ITS OWN pixel, the records stay in registers and
@@ -599,12 +607,12 @@ static int dispatch_gather(GatherArgs& a, int C, int G, hipStream_t stream) {
     return PMN_ERR_SHAPE;
 }
 
-extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, const float* rel_proj,
-                                  const float* depth_sample, const float* view_weights_in, int vw_shift,
-                                  const float* similarity_mlp, const float* pixelwise_mlp, int B, int N, int C, int G,
-                                  int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
-                                  int* vw_argmax_out, float* similarity_out, void* stream) {
-    if (!ref_nhwc || !src_nhwc || !rel_proj || !depth_sample || !similarity_mlp || !cost_out) return PMN_ERR_ARG;
+static int warp_correlate_impl(const float* ref_nhwc, const float* src_nhwc, const unsigned long long* src_table,
+                               const float* rel_proj, const float* depth_sample, const float* view_weights_in, int vw_shift,
+                               const float* similarity_mlp, const float* pixelwise_mlp, int B, int N, int C, int G,
+                               int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
+                               int* vw_argmax_out, float* similarity_out, void* stream) {
+    if (!ref_nhwc || (!src_nhwc && !src_table) || !rel_proj || !depth_sample || !similarity_mlp || !cost_out) return PMN_ERR_ARG;
     if (!view_weights_in && (!pixelwise_mlp || !view_weights_out)) return PMN_ERR_ARG;
     if (B < 1 || N < 1 || D < 1 || h < 2 || w < 2 || hs < 2 || ws < 2 || vw_shift < 0 || vw_shift > 2) return PMN_ERR_ARG;
     if (D > PMN_MAX_DEPTH) return PMN_ERR_SHAPE;
@@ -613,6 +621,7 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     memset(&a, 0, sizeof(a));
     a.ref = ref_nhwc;
     a.src = src_nhwc;
+    a.src_tab = src_table;
     a.proj = rel_proj;
     a.depth = depth_sample;
     a.vw_in = view_weights_in;
@@ -629,7 +638,7 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
     // key 1 -- bit 0 = windowed kernels where they cover the shape (the lane = item engine, or with bit 4 the first windowed
     // form), bits 2 / 3 keep the streaming kernel for the PixelwiseNet / the known-weights launches, bit 5 = the tile-window kernel.
     // The product library has none of this: every launch is the streaming kernel below.
-    const int flags = pmn_gather_flags();
+    const int flags = src_table ? 0 : pmn_gather_flags();  // (the research families read the stacked layout only)
     const bool pixelwise = view_weights_in == nullptr;
     if (flags & 64) {  // round 4: correlate-then-interpolate on the fp32 matrix cores (experimental/corr_mfma.hip)
         const int rc = pmn_launch_corr_mfma(a, C, G, pixelwise, (hipStream_t)stream);
@@ -647,6 +656,27 @@ extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, 
 #endif
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
+}
+
+extern "C" int pmn_warp_correlate(const float* ref_nhwc, const float* src_nhwc, const float* rel_proj,
+                                  const float* depth_sample, const float* view_weights_in, int vw_shift,
+                                  const float* similarity_mlp, const float* pixelwise_mlp, int B, int N, int C, int G,
+                                  int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
+                                  int* vw_argmax_out, float* similarity_out, void* stream) {
+    return warp_correlate_impl(ref_nhwc, src_nhwc, nullptr, rel_proj, depth_sample, view_weights_in, vw_shift, similarity_mlp,
+                               pixelwise_mlp, B, N, C, G, D, h, w, hs, ws, cost_out, view_weights_out, vw_argmax_out, similarity_out,
+                               stream);
+}
+
+extern "C" int pmn_warp_correlate_views(const float* ref_nhwc, const void* src_view_table, const float* rel_proj,
+                                        const float* depth_sample, const float* view_weights_in, int vw_shift,
+                                        const float* similarity_mlp, const float* pixelwise_mlp, int B, int N, int C, int G,
+                                        int D, int h, int w, int hs, int ws, float* cost_out, float* view_weights_out,
+                                        int* vw_argmax_out, float* similarity_out, void* stream) {
+    if (!src_view_table) return PMN_ERR_ARG;
+    return warp_correlate_impl(ref_nhwc, nullptr, static_cast<const unsigned long long*>(src_view_table), rel_proj, depth_sample,
+                               view_weights_in, vw_shift, similarity_mlp, pixelwise_mlp, B, N, C, G, D, h, w, hs, ws, cost_out,
+                               view_weights_out, vw_argmax_out, similarity_out, stream);
 }
 
 extern "C" int pmn_feature_weight(const float* ref_nhwc, const float* eval_offsets, const int* eval_table_host,

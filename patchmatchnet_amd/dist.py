@@ -40,6 +40,32 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
     return rank, world, device
 
 
+def bind_to_device_node(device: torch.device) -> str:
+    """Pins this process (and every thread it starts afterwards) to the CPUs of the NUMA node its GPU hangs off.  One process per GPU
+    on a two-socket host: the launch thread, the decode / writer pools and the pinned staging buffers (first touch) otherwise land on
+    either socket by chance -- measured on the 2 x 64-core bench box as whole eval.py runs alternating between 270 and 380
+    depth-maps/s (profiles/r04_eval_bench.md).  Returns a one-line description; never raises (no sysfs entry, no permission: no-op).
+    PMN_NUMA_BIND=0 disables it."""
+    if os.environ.get("PMN_NUMA_BIND", "1") == "0" or device.type != "cuda" or not hasattr(os, "sched_setaffinity"):
+        return "numa binding off"
+    try:
+        p = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        cpus: List[int] = []
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if node < 0 or not allowed:
+            return f"numa binding: {bdf} reports node {node}, nothing to bind to"
+        os.sched_setaffinity(0, allowed)
+        return f"bound to NUMA node {node} of {bdf}: {len(allowed)} cpus ({allowed[0]}..{allowed[-1]})"
+    except (OSError, ValueError, AttributeError, RuntimeError) as e:
+        return f"numa binding skipped ({type(e).__name__}: {e})"
+
+
 def block_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """[start, stop) of rank ``rank``'s block when n items are cut into ``world`` contiguous, near-equal blocks (the first
     n % world blocks are one longer)."""

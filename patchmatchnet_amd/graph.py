@@ -49,7 +49,8 @@ class GraphedForward:
     @classmethod
     def _signature(cls, images: Sequence[torch.Tensor], intrinsics: torch.Tensor, features) -> Tuple:
         feat = None if features is None else tuple(tuple((s, tuple(t.shape)) for s, t in sorted(f.items())) for f in features)
-        return tuple(tuple(i.shape) for i in images), cls._alias_pattern(images), tuple(intrinsics.shape), feat
+        return (tuple(tuple(i.shape) for i in images), cls._alias_pattern(images), tuple(intrinsics.shape), feat,
+                features is not None and cls._table_ok(features))
 
     def _capture(self, images, intrinsics, extrinsics, depth_min, depth_max, features):
         dev = intrinsics.device
@@ -61,7 +62,24 @@ class GraphedForward:
                       noise=torch.empty((images[0].shape[0], 48, images[0].shape[2] // 8, images[0].shape[3] // 8),
                                         dtype=torch.float32, device=dev),
                       features=None, features_nhwc=None)
-        if features is not None:
+        if features is not None and self._table_ok(features):
+            # injected pyramids that are channels-last maps of their own (eval.py's encode-once path): only the REFERENCE view's
+            # pyramid is copied into static buffers (offset heads, FeatureWeightNet and the cascade read it); the SOURCE views stay
+            # where FeatureNet wrote them and the captured pmn_warp_correlate_views launches find them through static device tables of
+            # addresses that _fill rewrites per sample (round 3 copied 0.53 GB of source pyramids per 1600x1200 sample into place)
+            from . import ops
+            B = images[0].shape[0]
+            stages = sorted(features[0])
+            ref = {s: torch.empty((B,) + tuple(features[0][s].shape[2:]) + (features[0][s].shape[1],), dtype=torch.float32, device=dev)
+                   for s in stages}
+            static["ref_nhwc"] = ref
+            static["tables"] = {s: ops.SourceTable(torch.zeros(len(features) - 1, dtype=torch.int64, device=dev),
+                                                   (len(features) - 1, B) + tuple(features[1][s].shape[2:]) + (features[1][s].shape[1],))
+                                for s in stages}
+            # (the source entries only carry the count and shapes of the views: stand-ins, so that no sample's pyramids are kept alive)
+            static["features"] = [{s: ref[s].permute(0, 3, 1, 2) for s in stages} for _ in range(len(features))]
+            static["table_host"] = []  # ring of pinned staging buffers, each guarded by an event
+        elif features is not None:
             # injected pyramids (eval.py's encode-once path): ONE channels-last buffer per stage holds all views, view-major -- the
             # layout the kernels read the source views from -- and the per-view NCHW-shaped tensors handed to forward() are views of
             # it: a sample's pyramids are copied once, into place (round 2 copied them into per-view buffers here and the forward
@@ -77,7 +95,7 @@ class GraphedForward:
         def run():
             return self.model(list(static["images"]), static["intrinsics"], static["extrinsics"], static["depth_min"],
                               static["depth_max"], features=static["features"], features_nhwc=static["features_nhwc"],
-                              noise=static["noise"])
+                              noise=static["noise"], source_tables=static.get("tables"), ref_nhwc_maps=static.get("ref_nhwc"))
 
         rng = torch.cuda.get_rng_state(dev)  # warm-up and capture must not advance the caller's random stream
         self._draw(static)
@@ -93,6 +111,23 @@ class GraphedForward:
             depth, confidence, _ = run()
         torch.cuda.set_rng_state(rng, dev)
         return graph, static, (depth, confidence)
+
+    @staticmethod
+    def _table_ok(features) -> bool:
+        """Every injected map is an NCHW-shaped view of a dense channels-last tensor of one size per stage (what FeatureNet.forward_hip
+        hands out): then the source views can be read in place through address tables."""
+        try:
+            for s in features[0]:
+                shapes = {tuple(f[s].shape) for f in features}
+                if len(shapes) != 1:
+                    return False
+                for f in features:
+                    t = f[s]
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.permute(0, 2, 3, 1).is_contiguous()):
+                        return False
+            return len(features) >= 2
+        except (AttributeError, KeyError, TypeError):
+            return False
 
     @staticmethod
     def _draw(static) -> None:
@@ -111,7 +146,27 @@ class GraphedForward:
         static["extrinsics"].copy_(extrinsics, non_blocking=True)
         static["depth_min"].copy_(depth_min, non_blocking=True)
         static["depth_max"].copy_(depth_max, non_blocking=True)
-        if features is not None:
+        if features is not None and "tables" in static:
+            for s, t in features[0].items():
+                static["features"][0][s].copy_(t, non_blocking=True)
+            stages = sorted(static["tables"])
+            n_src = len(features) - 1
+            ring = static["table_host"]
+            k = static["turn"] = (static.get("turn", -1) + 1) % 8
+            if k >= len(ring):
+                ring.append([torch.empty(len(stages) * n_src, dtype=torch.int64).pin_memory(), None])
+            host, ev = ring[k]
+            if ev is not None:
+                ev.synchronize()  # eight samples back: long done
+            for i, s in enumerate(stages):
+                for v in range(n_src):
+                    host[i * n_src + v] = features[1 + v][s].permute(0, 2, 3, 1).data_ptr()
+            for i, s in enumerate(stages):
+                static["tables"][s].table.copy_(host[i * n_src:(i + 1) * n_src], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(static["intrinsics"].device))
+            ring[k][1] = ev
+        elif features is not None:
             for dst, src in zip(static["features"], features):
                 for s, t in src.items():
                     dst[s].copy_(t, non_blocking=True)

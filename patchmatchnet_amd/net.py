@@ -332,14 +332,17 @@ class PatchmatchNet(nn.Module):
     def forward(self, images: List[torch.Tensor], intrinsics: torch.Tensor, extrinsics: torch.Tensor,
                 depth_min: torch.Tensor, depth_max: torch.Tensor, noise: Optional[torch.Tensor] = None,
                 features: Optional[List[Dict[int, torch.Tensor]]] = None, debug: Optional[dict] = None,
-                features_nhwc: Optional[Dict[int, torch.Tensor]] = None
+                features_nhwc: Optional[Dict[int, torch.Tensor]] = None, source_tables: Optional[Dict[int, "ops.SourceTable"]] = None,
+                ref_nhwc_maps: Optional[Dict[int, torch.Tensor]] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Dict[int, List[torch.Tensor]]]:
         """Reference arguments (images: N x [B,3,H,W]; intrinsics [B,N,3,3]; extrinsics [B,N,4,4]; depth_min/max [B]).
 
         Optional extras (default = reference behaviour): ``noise`` [B,48,H/8,W/8] pins the stage-3 random draw,
         ``features`` injects pre-computed FeatureNet outputs (``features_nhwc``: {stage: [(N+1)*B,h,w,C]} = the SAME maps, view-major
         in one channels-last buffer per stage -- what ``features[v][stage]`` are views of -- so that the kernels read them in place
-        instead of stacking the source views into a buffer of their own), ``debug`` (dict) collects per-stage intermediates.
+        instead of stacking the source views into a buffer of their own; or ``source_tables`` {stage: ops.SourceTable} +
+        ``ref_nhwc_maps`` {stage: [B,h,w,C]}: the source views stay wherever they are and the kernels find them through a device
+        table of addresses, pmn_warp_correlate_views), ``debug`` (dict) collects per-stage intermediates.
         Returns (depth [B,1,H,W], photometric confidence [B,H,W] (empty in training mode), {stage: [depths]})."""
         assert len(images) == intrinsics.size()[1], "Different number of images and intrinsic matrices"
         assert len(images) == extrinsics.size()[1], "Different number of images and extrinsic matrices"
@@ -393,7 +396,9 @@ class PatchmatchNet(nn.Module):
                 allv = ops.nchw_to_nhwc(stacked[stage].contiguous())
             else:
                 allv = None
-            if allv is not None:
+            if source_tables is not None:
+                ref_nhwc, src_nhwc = ref_nhwc_maps[stage], source_tables[stage]
+            elif allv is not None:
                 ref_nhwc = allv[:batch]
                 src_nhwc = allv[batch:].view(len(src_features), batch, *allv.shape[1:])
             depths, score, view_weights = pm(

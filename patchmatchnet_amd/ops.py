@@ -251,7 +251,28 @@ def init_hypotheses(noise: Optional[torch.Tensor], depth: Optional[torch.Tensor]
     return ds, xn
 
 
-def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: torch.Tensor, depth_sample: torch.Tensor,
+class SourceTable:
+    """The source views of a sample as a DEVICE table of per-view addresses (pmn_warp_correlate_views) instead of one stacked
+    [N,B,hs,ws,C] tensor: ``table`` int64 [N] on the device, entry v = data_ptr of view v's channels-last [B,hs,ws,C] map.  Duck-types
+    the stacked tensor where only its shape / device are read.  The maps themselves must outlive the launch (the caller holds them)."""
+
+    def __init__(self, table: torch.Tensor, shape) -> None:
+        if table.dtype != torch.int64 or not table.is_cuda or table.numel() != int(shape[0]):
+            raise PmnError("SourceTable: int64 device tensor with one address per source view")
+        self.table, self.shape, self.device = table, tuple(int(x) for x in shape), table.device
+
+    @staticmethod
+    def addresses(maps) -> list:
+        """data_ptr of every view's map after checking it is a dense channels-last [B,hs,ws,C] float32 device tensor."""
+        out = []
+        for m in maps:
+            if not (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous()):
+                raise PmnError("SourceTable: dense float32 channels-last device maps")
+            out.append(m.data_ptr())
+        return out
+
+
+def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc, rel_proj: torch.Tensor, depth_sample: torch.Tensor,
                    view_weights: Optional[torch.Tensor], vw_shift: int, similarity_mlp: torch.Tensor,
                    pixelwise_mlp: Optional[torch.Tensor], G: int, want_similarity: bool = False,
                    want_argmax: bool = False):
@@ -260,7 +281,9 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
     Returns (cost [B,D,h,w] (a hypothesis-last view: storage [B,h,w,D]), view_weights [B,N,h,w] (input passed through, or computed), argmax or None,
     aggregated similarity [B,G,D,h,w] or None)."""
     _dev(ref_nhwc, "ref_nhwc")
-    _dev(src_nhwc, "src_nhwc")
+    table = src_nhwc if isinstance(src_nhwc, SourceTable) else None
+    if table is None:
+        _dev(src_nhwc, "src_nhwc")
     _dev(rel_proj, "rel_proj")
     _dev(depth_sample, "depth_sample")
     B, h, w, C = ref_nhwc.shape
@@ -288,10 +311,11 @@ def warp_correlate(ref_nhwc: torch.Tensor, src_nhwc: torch.Tensor, rel_proj: tor
         if _TIMING is not None and _TIMING_ON:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(_lib.lib().pmn_warp_correlate(ref_nhwc.data_ptr(), src_nhwc.data_ptr(), rel_proj.data_ptr(),
-                                            depth_sample.data_ptr(), _ptr(view_weights), vw_shift, sim_p, pix_p, B, N, C,
-                                            G, D, h, w, hs, ws, cost.data_ptr(), _ptr(vw_out), _ptr(argmax), _ptr(sim),
-                                            _stream(cost)), "pmn_warp_correlate")
+        fn = _lib.lib().pmn_warp_correlate if table is None else _lib.lib().pmn_warp_correlate_views
+        check(fn(ref_nhwc.data_ptr(), (src_nhwc if table is None else table.table).data_ptr(), rel_proj.data_ptr(),
+                 depth_sample.data_ptr(), _ptr(view_weights), vw_shift, sim_p, pix_p, B, N, C,
+                 G, D, h, w, hs, ws, cost.data_ptr(), _ptr(vw_out), _ptr(argmax), _ptr(sim),
+                 _stream(cost)), "pmn_warp_correlate")
         if _TIMING is not None and _TIMING_ON:
             ev1.record()
             _TIMING.append((ev0, ev1, 4 * B * h * w * ((1 + N) * C + D + N + G * D),

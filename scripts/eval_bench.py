@@ -28,8 +28,11 @@ base = "/dev/shm/pmn_eval_bench" if os.path.isdir("/dev/shm") else "/tmp/pmn_eva
 shutil.rmtree(base, ignore_errors=True)
 data = os.path.join(base, "data")
 t0 = time.time()
-for s in range(n_scans):
+n_render = min(n_scans, int(os.environ.get("PMN_EVAL_BENCH_RENDER", "6")))  # distinct scenes; the rest are copies (steady-state runs)
+for s in range(n_render):
     synth.write_scene_scan(data, "scan%d" % (s + 1), n_views, 1200, 1600, n_src=10, seed=s, device="cuda")
+for s in range(n_render, n_scans):
+    shutil.copytree(os.path.join(data, "scan%d" % (s % n_render + 1)), os.path.join(data, "scan%d" % (s + 1)))
 with open(os.path.join(data, "list.txt"), "w") as f:
     f.write("".join("scan%d\n" % (s + 1) for s in range(n_scans)))
 print("generated %d scans x %d views in %.1f s, %.1f MB of JPEG" % (
@@ -59,9 +62,28 @@ one = os.path.join(data, "one.txt")
 open(one, "w").write("scan1\n")
 run("warmup", ["--decode_threads", "8"], scan_list=one)  # library load, weight packing, graph capture, page cache
 results = []
-for threads in (4, 8, 16):
-    results.append(run("decode_threads%d" % threads, ["--decode_threads", str(threads)]))
-results.append(run("default_flags", []))
+if "--steady" in sys.argv:  # the steady-state figure: the default flags, several times over all scans (spread = max/min - 1)
+    for r in range(4):
+        results.append(run("default_flags_run%d" % (r + 1), []))
+    vals = [r["depth_maps_per_s"] for r in results]
+    print("STEADY " + json.dumps({"runs": vals, "median": sorted(vals)[len(vals) // 2], "spread": round(max(vals) / min(vals) - 1, 3),
+                                  "samples_per_run": results[0]["samples"], "seconds_per_run": [r["seconds"] for r in results]}), flush=True)
+    if os.environ.get("PMN_EVAL_BENCH_QUICK", "") != "1":
+        for extra in (["--in_flight", "3"], ["--in_flight", "1"], ["--writer_threads", "8"], ["--writer_threads", "16"]):
+            results.append(run("default_" + "_".join(extra).replace("--", ""), extra))
+    if os.environ.get("PMN_EVAL_BENCH_SWEEP", "") == "1":
+        for th in (8, 12, 16, 24):
+            for r in range(3):
+                results.append(run("decode_threads%d_run%d" % (th, r + 1), ["--decode_threads", str(th)]))
+    # the same pipeline with the map files discarded by the writer threads (PMN_EVAL_DISCARD_MAPS=1): download included, file system out
+    pm_eval._DISCARD_MAPS = True
+    for r in range(4):
+        results.append(run("discard_maps_run%d" % (r + 1), []))
+    pm_eval._DISCARD_MAPS = False
+else:
+    for threads in (4, 8, 16):
+        results.append(run("decode_threads%d" % threads, ["--decode_threads", str(threads)]))
+    results.append(run("default_flags", []))
 if "--both" in sys.argv:  # inference + consistency filtering + fusion (masks, fused.ply) of every scan
     results.append(run("output_type_both", ["--output_type", "both", "--geo_mask_thres", "3"]))
     results.append(run("output_type_both_1thread", ["--output_type", "both", "--geo_mask_thres", "3", "--decode_threads", "1"]))

@@ -952,3 +952,29 @@ def test_integration_stub_warps_like_the_op():
     got = ns["differentiable_warping"](t(g["A_src"]), t(g["A_src_proj"]), t(g["A_ref_proj"]), t(g["A_depth"]))
     torch.cuda.synchronize()
     assert GU.abs_err(n(got), g["A_warped"]) < 5e-5
+
+
+def test_warp_correlate_views_reads_the_sources_in_place():
+    """pmn_warp_correlate_views (source views through a device table of per-view addresses) == pmn_warp_correlate on the stacked
+    tensor, bit for bit, known weights and PixelwiseNet, batch of two."""
+    P = _gpu()
+    from patchmatchnet_amd import _lib
+    gen = torch.Generator().manual_seed(4)
+    B, N, C, G, D, h, w = 2, 3, 32, 8, 16, 21, 36
+    intr, extr = synth.synthetic_cameras(N + 1, h * 8, w * 8)
+    proj = synth.stage_projections(intr, extr, 0.125)
+    P0 = torch.from_numpy(proj[0, 0]).double()
+    rel = torch.stack([torch.from_numpy(proj[0, i]).double() @ torch.inverse(P0) for i in range(1, N + 1)], 0).float()
+    rel = rel[None].repeat(B, 1, 1, 1).contiguous().to(DEV)
+    ref = torch.randn(B, h, w, C, generator=gen).to(DEV)
+    views = [torch.randn(B, h, w, C, generator=gen).to(DEV) for _ in range(N)]  # separately allocated, as a feature cache holds them
+    stacked = torch.stack(views, 0).contiguous()
+    lo, hi = 1 / 935.0, 1 / 425.0
+    depth = (1.0 / (lo + torch.rand(B, D, h, w, generator=gen) * (hi - lo))).sort(dim=1)[0].contiguous().to(DEV)
+    mlp = lambda s: (0.4 * torch.randn(_lib.MLP_FLOATS, generator=torch.Generator().manual_seed(s))).to(DEV)
+    table = P.ops.SourceTable(torch.tensor(P.ops.SourceTable.addresses(views), dtype=torch.int64, device=DEV), stacked.shape)
+    for vw in (torch.rand(B, N, h, w, generator=gen).to(DEV), None):
+        a = P.ops.warp_correlate(ref, stacked, rel, depth, vw, 0, mlp(1), None if vw is not None else mlp(2), G, want_similarity=True)
+        b = P.ops.warp_correlate(ref, table, rel, depth, vw, 0, mlp(1), None if vw is not None else mlp(2), G, want_similarity=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[1], b[1])
