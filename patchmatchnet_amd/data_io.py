@@ -14,9 +14,10 @@ from PIL import Image
 
 def _linear_taps(dst: int, src: int):
     """Source index pairs and float32 weights of OpenCV's resize(INTER_LINEAR) along one axis (imgproc/src/resize.cpp,
-    cv::resize -> the generic ResizeFunc set-up): scale = src / dst in double; fx = (float)((d + 0.5) * scale - 0.5);
+    cv::resize -> the generic ResizeFunc set-up): inv_scale = dst / src and scale = 1 / inv_scale, both in double (NOT src / dst: the
+    two can differ in the last bit and move a sample that sits exactly on an integer position); fx = (float)((d + 0.5) * scale - 0.5);
     s = floor(fx); fx -= s; s < 0 -> (s, fx) = (0, 0); s >= src - 1 -> (s, fx) = (src - 1, 0); weights (1 - fx, fx) in float32."""
-    scale = float(src) / float(dst)
+    scale = 1.0 / (float(dst) / float(src))
     f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     s0 = np.floor(f).astype(np.int64)
     f = (f - s0.astype(np.float32)).astype(np.float32)
@@ -38,6 +39,12 @@ def resize_bilinear(image: np.ndarray, height: int, width: int) -> np.ndarray:
     MVSDataset flow around it.  image [H,W] or [H,W,C] float32."""
     H, W = image.shape[:2]
     image = np.asarray(image, np.float32)
+    if H == 2 * height and W == 2 * width:
+        # cv::resize turns INTER_LINEAR into INTER_AREA for an exact 2x down-scale ("INTER_AREA (fast) also is equal to INTER_LINEAR",
+        # resize.cpp): the 2x2 block summed in float32 in the order (y,x), (y,x+1), (y+1,x), (y+1,x+1), times 0.25f -- the generic
+        # ResizeAreaFast path; OpenCV's SIMD builds may associate the sum differently (unpinned, like the rest of this function)
+        s4 = ((image[0::2, 0::2] + image[0::2, 1::2]) + image[1::2, 0::2]) + image[1::2, 1::2]
+        return (s4 * np.float32(0.25)).astype(np.float32)
     y0, y1, b0, b1 = _linear_taps(height, H)
     x0, x1, a0, a1 = _linear_taps(width, W)
     if image.ndim == 3:

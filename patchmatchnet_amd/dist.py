@@ -30,7 +30,15 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, torch.device]:
     # below runs through it -- one rank over RCCL exercises the same library path as eight
     if "WORLD_SIZE" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29578")
+        if "MASTER_PORT" not in os.environ:
+            # a launcher sets the port; without one, several ranks cannot agree on a port by themselves (fail instead of colliding
+            # with another job on a fixed default), and a single rank takes a free ephemeral one
+            if world > 1:
+                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: launch with torch.distributed.run (or set MASTER_PORT)")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         # PMN_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests/test_eval_gpu.py: RCCL needs a device per rank)
         backend = os.environ.get("PMN_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if backend == "nccl":
