@@ -338,7 +338,7 @@ def main():
     launched = "WORLD_SIZE" in os.environ  # by torch.distributed.run / self_launch: then the process group exists even for one rank
     if launched:                            # (world 1 over RCCL exercises the same init / collectives as world 8: tests/test_bench_gpu.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("MASTER_PORT", "29577")  # (the driver and self_launch pass their own)
         # nccl (= RCCL over xGMI) is the product's backend; PMN_DIST_BACKEND=gloo exists so that the multi-rank control flow can be
         # exercised with several ranks on ONE GPU (collectives then stage through the host)
         backend = os.environ.get("PMN_DIST_BACKEND", "nccl")

@@ -3,7 +3,10 @@
 //
 // Why.  gfx950's fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate, 1/16 of v_mfma_f32_16x16x32_f16, and there is
 // no xf32 form.  Every value is split on the fly into two fp16 numbers,
-//       x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)            (22 significant bits; lo stays in fp16's normal range)
+//       x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)            (22 significant bits for 6.1e-5 <= |x| < 65504;
+//       below that hi is a subnormal and the ABSOLUTE error stays <= 3e-8 per factor; at |x| >= 65504 hi = inf and the result is
+//       inf / NaN -- the kernel does not check: weights are checked when packed, activations are the caller's contract, see the
+//       "fp16-split entry points" paragraph of include/pmn_hip.h)
 // and the convolution is evaluated as
 //       sum x*w  ~=  sum hi_x*hi_w  +  ( sum hi_x*lo_w + sum lo_x*hi_w ) / 2048        (the lo*lo term, 2^-22, is dropped)
 // Products of two fp16 numbers are exact in fp32 and the MFMA accumulates in fp32, so the result carries 2-4e-7 of the output scale
