@@ -239,7 +239,7 @@ __global__ __launch_bounds__(PIXELWISE ? 512 : 64 * NW) __attribute__((amdgpu_wa
 
     // ---- projection of the lane's items into view v + the window of the wave's live taps ---------------------------------
     auto prepare = [&](CmTask& T, const int v) __attribute__((always_inline)) {
-        const PmnPose pose = pmn_make_pose(plds + v * 16, xf, yf);  // the reference's own warp chain (pmn_common.hpp)
+        const PmnPose pose = pmn_make_pose(plds + v * 16, xf, yf, h, w);  // the reference's own warp chain (pmn_common.hpp)
         int lox = 0x7fffffff, loy = 0x7fffffff, hix = -0x7fffffff, hiy = -0x7fffffff;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {

@@ -92,8 +92,8 @@ __device__ __forceinline__ float lane_blend_dot(const pmn_f4 t00, const pmn_f4 t
 
 using LanePose = PmnPose;  // the reference's own warp chain (pmn_common.hpp): round 4 replaced the v_rcp projection everywhere
 
-__device__ __forceinline__ LanePose lane_make_pose(const float* __restrict__ P, float xf, float yf, float, float) {
-    return pmn_make_pose(P, xf, yf);
+__device__ __forceinline__ LanePose lane_make_pose(const float* __restrict__ P, float xf, float yf, int h, int w) {
+    return pmn_make_pose(P, xf, yf, h, w);
 }
 
 // Tap record of one item.  The general path is gather_corr.hip's (behind-camera sentinel, module.py:166-169; border handling
@@ -323,7 +323,6 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
         for (int k = 0; k < G; ++k) sims[s][k] = pmn_f2{0.0f, 0.0f};
     float wtot = 1e-5f;
 
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
     const float xf = (float)x, yf = (float)y;
     const int wv = w >> a.vw_shift, hwv = (h >> a.vw_shift) * wv;
     const int vw_idx = (y >> a.vw_shift) * wv + (x >> a.vw_shift);
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(PMN_BLOCK, WPS) void gather_lane_kernel(const Gathe
     if (MODE == MODE_AGG && ok) vw_next = a.vw_in[((size_t)b * N) * hwv + vw_idx];
 
     for (int v = 0; v < N; ++v) {
-        const LanePose q = lane_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, sxs, sys);
+        const LanePose q = lane_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
         const float vw = vw_next;
         if (MODE == MODE_AGG && ok && v + 1 < N) vw_next = a.vw_in[((size_t)b * N + v + 1) * hwv + vw_idx];
         if (MODE == MODE_AGG) wtot += vw;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void gather_tile_kernel(const GatherA
     // Tap records of the thread's hypotheses for view v, the tile's window (bounding box of every tap, cut down when it does not
     // fit a window buffer) and the records parked in record buffer `rb`.  Contains ONE workgroup barrier.
     auto prepare_view = [&](const int v, const int rb) -> Geom {
-        const PmnPose pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);  // the reference's own warp chain (round 4)
+        const PmnPose pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);  // the reference's own warp chain (round 4)
         PmnTapsXY rec[NR];
         bool rv[NR];
         int lo_x = BIG, hi_x = -BIG, lo_y = BIG, hi_y = -BIG;

@@ -88,8 +88,8 @@ __device__ __forceinline__ float blend_dot(const pmn_f4 t00, const pmn_f4 t01, c
 
 using PosePix = PmnPose;  // the reference's own warp chain (pmn_common.hpp): round 4 replaced the v_rcp projection everywhere
 
-__device__ __forceinline__ PosePix make_pose_pix(const float* __restrict__ P, float xf, float yf, float, float) {
-    return pmn_make_pose(P, xf, yf);
+__device__ __forceinline__ PosePix make_pose_pix(const float* __restrict__ P, float xf, float yf, int h, int w) {
+    return pmn_make_pose(P, xf, yf, h, w);
 }
 
 // Tap record of one item; returns false (zero weights, corner (0,0)) for an inactive lane or a hypothesis behind the source
@@ -303,13 +303,12 @@ __global__ __launch_bounds__(PMN_BLOCK, 3) void gather_win_views_kernel(const Ga
 #pragma unroll
         for (int k = 0; k < GPS; ++k) acc[s][k] = 0.0f;
 
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
     const float xf = (float)x, yf = (float)y;
     const int wv = w >> a.vw_shift, hwv = (h >> a.vw_shift) * wv;
     const int vw_idx = (y >> a.vw_shift) * wv + (x >> a.vw_shift);
 
     for (int v = 0; v < N; ++v) {
-        const PosePix q = make_pose_pix(a.proj + ((size_t)b * N + v) * 16, xf, yf, sxs, sys);
+        const PosePix q = make_pose_pix(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
         pmn_glb_char* src_slice = (pmn_glb_char*)a.src + (((size_t)(v * a.B + b) * hs * ws) * (C * 4) + slice * 64);
         const float vw = ok ? a.vw_in[((size_t)b * N + v) * hwv + vw_idx] : 0.0f;
         PmnTapsXY ta, tb;
@@ -455,7 +454,6 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_win_pixelwise_kernel(const G
         refq[j] = pmn_f4{0.f, 0.f, 0.f, 0.f};
         if (ok) refq[j] = PMN_GLB_F4((pmn_glb_char*)a.ref + (((size_t)b * hw + p) * (C * 4) + slice * 64 + ofs[j]));
     }
-    const float sxs = (float)(ws - 1) / (float)(w - 1), sys = (float)(hs - 1) / (float)(h - 1);
     const float xf = (float)x, yf = (float)y;
 
     // item role: a fixed pixel of the tile, hypotheses dA0 + j * DSTEP
@@ -473,7 +471,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void gather_win_pixelwise_kernel(const G
 
     for (int v = 0; v < N; ++v) {
         if (tid < NPIX) vwkey[tid] = 0ull;
-        const PosePix q = make_pose_pix(a.proj + ((size_t)b * N + v) * 16, xf, yf, sxs, sys);
+        const PosePix q = make_pose_pix(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
         pmn_glb_char* src_slice = (pmn_glb_char*)a.src + (((size_t)(v * a.B + b) * hs * ws) * (C * 4) + slice * 64);
         for (int dc0 = 0; dc0 < D; dc0 += 8) {
             const int da = dc0 + dsub, db = da + 4;

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
 
     // (the warp itself: pmn_make_pose / pmn_pose_position of pmn_common.hpp -- the reference's own IEEE chain)
     using Pose = PmnPose;
-    auto make_pose = [&](const float* P) { return pmn_make_pose(P, (float)xA, (float)yA); };
+    auto make_pose = [&](const float* P) { return pmn_make_pose(P, (float)xA, (float)yA, h, w); };
 
     // phase A for one view / hypothesis range [d_lo, d_hi): records land at rec_base + (d - d_lo)*NPIX + pixA
     auto phase_a = [&](const Pose& q, int d_lo, int d_hi, int rec_base) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             rdep[j] = (okB && d < D) ? a.depth[((size_t)b * D + d) * hw + pB] : -1.0f;
         }
         for (int v = 0; v < N; ++v) {
-            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);
+            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
             float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
             int roff[RPL];
 #pragma unroll
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void g
             // view's similarity tile is filled (round 1 walked 32 hypotheses at a time behind 4 barriers per view).
             constexpr int RPL = DT / LPI;
             const float xf = (float)xB, yf = (float)yB;
-            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf);
+            const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
             float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
             int roff[RPL];
 #pragma unroll

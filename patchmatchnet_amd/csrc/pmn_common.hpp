@@ -104,9 +104,32 @@ __device__ __forceinline__ float pmn_unnorm_noalign(float c, int size) {
 // positions within 1e-4 px of these, and exactly that was 9 of 10 of the free-running outlier pixels against the reference's own
 // output (6.5e-4 -> 7.3e-5 of the final-depth pixels beyond 1e-3 at 1600x1200; profiles/r04_ieee_attribution.md).
 // P = relative projection src_proj @ inv(ref_proj), row-major 4x4.
-struct PmnPose { float rx, ry, rz, tx, ty, tz; };  // rot_xyz of one reference pixel for one view, and the translation
+struct PmnPose {
+    float rx, ry, rz, tx, ty, tz;  // rot_xyz of one reference pixel for one view, and the translation
+    float cx, cy, rcx, rcy;        // the normalisation divisors (w-1)/2, (h-1)/2 and their refined reciprocals
+};
 
-__device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y) {
+// IEEE fp32 division the way hipcc expands it (LLVM's LowerFDIV32: v_rcp_f32, one Newton refinement of the reciprocal, the quotient
+// with two fma corrections), WITHOUT its v_div_scale / v_div_fmas / v_div_fixup shell: that shell only acts on operands whose
+// exponents are extreme (denormal denominators, |numerator| < 2^-103, quotients near overflow) -- never on depths, pixel coordinates
+// or image sizes -- so for every operand this file divides the sequence below IS the compiler's, bit for bit, at 8 instead of 12
+// instructions, and its first three (the refined reciprocal) are shared by divisions with a common denominator.  The warp has four
+// divisions per (pixel, hypothesis, view): 48 -> 23 instructions (round 4: profiles/r04_ieee_attribution.md).
+__device__ __forceinline__ float pmn_rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float pmn_div_by(float n, float d, float r) {  // n / d with r = pmn_rcp_refined(d)
+#pragma clang fp contract(off)
+    const float q0 = n * r;
+    const float e2 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e2, r, q0);
+    const float e3 = fmaf(-d, q1, n);
+    return fmaf(e3, r, q1);
+}
+
+__device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y, int h, int w) {
 #pragma clang fp contract(off)
     PmnPose q;
     q.rx = (P[0] * x + P[1] * y) + P[2];
@@ -115,6 +138,10 @@ __device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, fl
     q.tx = P[3];
     q.ty = P[7];
     q.tz = P[11];
+    q.cx = (float)(w - 1) / 2.0f;
+    q.cy = (float)(h - 1) / 2.0f;
+    q.rcx = pmn_rcp_refined(q.cx);
+    q.rcy = pmn_rcp_refined(q.cy);
     return q;
 }
 
@@ -130,9 +157,9 @@ __device__ __forceinline__ bool pmn_pose_position(const PmnPose& q, float d, int
         py = (float)h;
         pz = 1.0f;
     }
-    float gx = px / pz, gy = py / pz;
-    float xn = gx / ((float)(w - 1) / 2.0f) - 1.0f;
-    float yn = gy / ((float)(h - 1) / 2.0f) - 1.0f;
+    const float rz = pmn_rcp_refined(pz);
+    const float gx = pmn_div_by(px, pz, rz), gy = pmn_div_by(py, pz, rz);                  // proj_xyz[:, :2] / z
+    const float xn = pmn_div_by(gx, q.cx, q.rcx) - 1.0f, yn = pmn_div_by(gy, q.cy, q.rcy) - 1.0f;  // x / ((w - 1) / 2) - 1
     ix = pmn_unnorm_align(xn, ws);
     iy = pmn_unnorm_align(yn, hs);
     return front;
@@ -140,7 +167,7 @@ __device__ __forceinline__ bool pmn_pose_position(const PmnPose& q, float d, int
 
 __device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, float x, float y, float d, int h,
                                                   int w, int hs, int ws, float& ix, float& iy) {
-    const PmnPose q = pmn_make_pose(P, x, y);
+    const PmnPose q = pmn_make_pose(P, x, y, h, w);
     pmn_pose_position(q, d, h, w, hs, ws, ix, iy);
 }
 

@@ -293,3 +293,72 @@ def test_point_colours_are_the_decoded_bytes():
     k = np.arange(256, dtype=np.uint8)
     img = np.array(k, dtype=np.float32) / 255.0
     np.testing.assert_array_equal((img * 255).astype(np.uint8), k)
+
+
+# ---- round 4 host logic ---------------------------------------------------------------------------------------------------------
+
+def test_resize_exact_half_takes_the_area_path_and_other_scales_use_opencvs_scale():
+    """cv::resize(INTER_LINEAR) switches to INTER_AREA for an exact 2x down-scale (resize.cpp) and otherwise derives its source
+    step as 1 / (dst / src) in double (reference datasets/data_io.py:26-29 calls it through cv2.resize)."""
+    from patchmatchnet_amd import data_io
+    rng = np.random.default_rng(0)
+    img = rng.random((12, 16, 3)).astype(np.float32)
+    got = data_io.resize_bilinear(img, 6, 8)
+    want = (((img[0::2, 0::2] + img[0::2, 1::2]) + img[1::2, 0::2]) + img[1::2, 1::2]) * np.float32(0.25)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    # not an exact half: half-pixel-centre bilinear taps; 7 -> 3 samples columns 0.6667, 3.0, 5.3333
+    s0, s1, w0, w1 = data_io._linear_taps(3, 7)
+    assert list(s0) == [0, 3, 5] and list(s1) == [1, 4, 6]
+    assert abs(float(w1[0]) - 2.0 / 3.0) < 1e-6 and float(w1[1]) == 0.0  # 3.0 exactly: the integer position keeps weight 0 on the right
+
+
+def test_single_rank_rendezvous_takes_a_free_port_and_several_ranks_need_one(monkeypatch):
+    """dist.init_from_env: WORLD_SIZE=1 without MASTER_PORT binds an ephemeral port (two single-rank jobs on one host used to collide
+    on a fixed default); WORLD_SIZE>1 without MASTER_PORT is an error instead of a silent default."""
+    import torch.distributed as tdist
+    from patchmatchnet_amd import dist as pdist
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        pdist.init_from_env("cpu")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    try:
+        rank, world, device = pdist.init_from_env("cpu")
+        assert (rank, world, device.type) == (0, 1, "cpu") and tdist.is_initialized()
+        assert int(os.environ["MASTER_PORT"]) > 1024
+    finally:
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
+        os.environ.pop("MASTER_PORT", None)
+    assert pdist.bind_to_device_node(torch.device("cpu")) == "numa binding off"
+
+
+def test_f16_split_refuses_weights_outside_float16s_range_and_the_modules_fall_back():
+    """params.split_f16 raises F16DomainError at |x| >= 65504; FeatureNet / Refinement then pack without the fp16-split operands,
+    remember why, and warn (the forward itself needs a GPU: tests/test_hip_parity.py)."""
+    import warnings
+    import patchmatchnet_amd as P
+    from patchmatchnet_amd import params as PP
+    hi, lo = PP.split_f16(np.array([1.0, -3.5e4, 6.0e-8]))
+    assert hi.dtype == np.float16 and np.isfinite(hi).all() and np.isfinite(lo).all()
+    for bad in (65504.0, -7.0e4, np.inf, np.nan):
+        with pytest.raises(PP.F16DomainError):
+            PP.split_f16(np.array([0.5, bad]))
+    net = P.net.FeatureNet().eval()
+    with torch.no_grad():
+        net.conv6.bn.weight.fill_(5.0e7)
+        net.conv6.bn.running_var.fill_(1.0)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        pk = net._packed()
+    assert net.f16_domain_error is not None and "conv6" in net.f16_domain_error
+    assert not any(k.endswith("_f16s") for k in pk) and any("fp32 kernels" in str(w.message) for w in caught)
+    ok = P.net.FeatureNet().eval()
+    assert ok.f16_domain_error is None and "conv6_f16s" in ok._packed() and ok.f16_domain_error is None
+    ref = P.net.Refinement().eval()
+    with torch.no_grad():
+        ref.conv3.bn.weight.fill_(9.0e7)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert "conv3_f16s" not in ref._packed() and "conv3" in ref.f16_domain_error
