@@ -17,6 +17,14 @@ timeout 300 python bench.py --no-cpu-baseline --width 1920 --height 1056 --views
 timeout 300 python bench.py --no-cpu-baseline --width 3072 --height 2048 --views 10 --samples 3 --steps 40 2>/dev/null | grep '^{' > $E/r04_bench_cfg5.json
 bash scripts/gpu_profile.sh 20 > $E/profile_eager.log 2>&1; cp gpurun_out/prof_summary/bench_kernel_stats.csv $E/r04_bench_kernel_stats.csv
 rm -rf gpurun_out/prof gpurun_out/prof_summary
+for cfg in "cfg3 1920 1056 7" "cfg5 3072 2048 10"; do
+  set -- $cfg
+  rm -rf $E/prof; mkdir -p $E/prof
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof -o bench -- \
+      python $R/bench.py --width $2 --height $3 --views $4 --samples 2 --steps 10 --warmup 2 --no-cpu-baseline --eager --settle-seconds 0.2 --steady-seconds 0 --roofline-steps 8 > $E/prof_$1.log 2>&1)
+  for f in $(find $E/prof -name "*kernel_stats.csv"); do cp $f $E/r04_bench_$1_kernel_stats.csv; done
+  rm -rf $E/prof
+done
 bash scripts/gpu_pmc_bench.sh > $E/pmc_bench.log 2>&1; cp gpurun_out/pmc_bench/summary.txt $E/r04_pmc_all_kernels.txt; rm -rf gpurun_out/pmc_bench
 timeout 2400 python -m pytest tests/ -q -m gpu --durations=6 2>&1 | tail -16 > $E/r04_pytest_gpu.log
 PMN_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_corr_mfma.py tests/test_gather_win.py tests/test_hip_parity.py -q -m gpu -k "corr or gather or windowed or winograd or mfma or research" 2>&1 | tail -3 >> $E/r04_pytest_gpu.log
