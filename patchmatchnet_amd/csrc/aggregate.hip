@@ -149,12 +149,55 @@ __device__ __forceinline__ float sigmoid_rcp(float x) {  // 1 / (1 + exp(-x)) fo
     return r * fmaf(-d, r, 2.0f);
 }
 
-// ---- main kernel: D % 4 == 0, thread = (pixel, hypothesis quad) ------------------------------------------------------------
+// Broadcast `v` from lane SL of every aligned group of G lanes (G, SL compile-time): one DPP move (two for 8-lane groups, the two
+// halves of a 16-lane DPP row), no LDS.  Every lane of the wave is active where this is called.
+template <int G, int SL>
+__device__ __forceinline__ int agg_group_bcast_i(int v) {
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lane groups inside a DPP row");
+    if constexpr (G == 2) {
+        return __builtin_amdgcn_mov_dpp(v, SL | (SL << 2) | ((2 + SL) << 4) | ((2 + SL) << 6), 0xF, 0xF, true);  // quad_perm
+    } else if constexpr (G == 4) {
+        return __builtin_amdgcn_mov_dpp(v, SL | (SL << 2) | (SL << 4) | (SL << 6), 0xF, 0xF, true);
+    } else if constexpr (G == 16) {
+        return __builtin_amdgcn_mov_dpp(v, 0x150 + SL, 0xF, 0xF, true);  // row_newbcast
+    } else {
+        const int lo = __builtin_amdgcn_update_dpp(v, v, 0x150 + SL, 0xF, 0x3, false);   // banks 0-1 = lanes 0..7 of the row
+        return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + SL, 0xF, 0xC, false);      // banks 2-3 = lanes 8..15
+    }
+}
+template <int G, int SL>
+__device__ __forceinline__ float agg_group_bcast_f(float v) {
+    return __int_as_float(agg_group_bcast_i<G, SL>(__float_as_int(v)));
+}
+
+// The K tap sets of one pixel (offset + 4 corner weights + feature weight; ~80 VALU instructions each: position, border clip,
+// floor, corner logic) do not depend on the hypothesis, and the DQ = D/4 threads of a pixel are adjacent lanes of one wave: with
+// DQT > 0 (= DQ, a power of two <= 16: the cascade's D = 8, 16, 32, 64) thread q forms only the tap sets k = q, q + DQ, ... and the
+// group exchanges them by DPP broadcasts (6 moves per tap set) -- 9 tap sets per PIXEL instead of per thread, which was a third of
+// this kernel's instructions.  Same values, so the results are bit-identical to DQT = 0 (every thread forms all K; any D % 4 == 0).
 template <int KMAX>
+__device__ __forceinline__ void agg_form_tap_set(const AggArgs& a, int b, int k, int p, int x, int y, int& off, float& w00, float& w01,
+                                                 float& w10, float& w11, float& fw) {
+    const int h = a.h, w = a.w, hw = h * w, K = a.K;
+    const float ox = a.offsets[((size_t)b * 2 * K + 2 * k) * hw + p];
+    const float oy = a.offsets[((size_t)b * 2 * K + 2 * k + 1) * hw + p];
+    float ix, iy;
+    pmn_neighbor_position((float)x, (float)y, a.table[2 * k], a.table[2 * k + 1], ox, oy, h, w, ix, iy);
+    const PmnTaps t = pmn_make_taps(ix, iy, h, w);
+    off = t.off;
+    w00 = t.w00;
+    w01 = t.w01;
+    w10 = t.w10;
+    w11 = t.w11;
+    fw = a.fweight[((size_t)b * K + k) * hw + p];
+}
+
+// ---- main kernel: D % 4 == 0, thread = (pixel, hypothesis quad) ------------------------------------------------------------
+template <int KMAX, int DQT>
 __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regress_q4_kernel(const AggArgs a) {
 #pragma clang fp contract(off)
     __shared__ float red[PMN_BLOCK];
-    const int h = a.h, w = a.w, hw = h * w, D = a.D, K = a.K, DQ = D >> 2;
+    const int h = a.h, w = a.w, hw = h * w, D = a.D, K = a.K, DQ = DQT > 0 ? DQT : D >> 2;
     const int npx = blockDim.x / DQ;  // host: blockDim.x = npx * DQ
     const int px = threadIdx.x / DQ, q = threadIdx.x - px * DQ;
     const int p_raw = blockIdx.x * npx + px;
@@ -165,22 +208,37 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
 
     int off[KMAX];
     float w00[KMAX], w01[KMAX], w10[KMAX], w11[KMAX], fw[KMAX];
+    if constexpr (DQT > 1) {
+        constexpr int KPT = (KMAX + DQT - 1) / DQT;  // tap sets formed by this thread: k = q + i DQT
+        int moff[KPT];
+        float m00[KPT], m01[KPT], m10[KPT], m11[KPT], mfw[KPT];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        off[k] = 0;
-        w00[k] = w01[k] = w10[k] = w11[k] = fw[k] = 0.0f;
-        if (k < K) {
-            const float ox = a.offsets[((size_t)b * 2 * K + 2 * k) * hw + p];
-            const float oy = a.offsets[((size_t)b * 2 * K + 2 * k + 1) * hw + p];
-            float ix, iy;
-            pmn_neighbor_position((float)x, (float)y, a.table[2 * k], a.table[2 * k + 1], ox, oy, h, w, ix, iy);
-            const PmnTaps t = pmn_make_taps(ix, iy, h, w);
-            off[k] = t.off;
-            w00[k] = t.w00;
-            w01[k] = t.w01;
-            w10[k] = t.w10;
-            w11[k] = t.w11;
-            fw[k] = a.fweight[((size_t)b * K + k) * hw + p];
+        for (int i = 0; i < KPT; ++i) {
+            const int k = q + i * DQT;
+            moff[i] = 0;
+            m00[i] = m01[i] = m10[i] = m11[i] = mfw[i] = 0.0f;
+            if (k < K) agg_form_tap_set<KMAX>(a, b, k, p, x, y, moff[i], m00[i], m01[i], m10[i], m11[i], mfw[i]);
+        }
+        // static (slot, source lane) per k: slot = k / DQT, lane = k % DQT
+#define AGG_TAKE(k_)                                                                                         \
+    if constexpr ((k_) < KMAX) {                                                                               \
+        constexpr int sl_ = (k_) % DQT, it_ = (k_) / DQT;                                                      \
+        off[k_] = agg_group_bcast_i<DQT, sl_>(moff[it_]);                                                      \
+        w00[k_] = agg_group_bcast_f<DQT, sl_>(m00[it_]);                                                       \
+        w01[k_] = agg_group_bcast_f<DQT, sl_>(m01[it_]);                                                       \
+        w10[k_] = agg_group_bcast_f<DQT, sl_>(m10[it_]);                                                       \
+        w11[k_] = agg_group_bcast_f<DQT, sl_>(m11[it_]);                                                       \
+        fw[k_] = agg_group_bcast_f<DQT, sl_>(mfw[it_]);                                                        \
+    }
+        AGG_TAKE(0) AGG_TAKE(1) AGG_TAKE(2) AGG_TAKE(3) AGG_TAKE(4) AGG_TAKE(5) AGG_TAKE(6) AGG_TAKE(7) AGG_TAKE(8)
+        static_assert(KMAX <= 9, "AGG_TAKE list");
+#undef AGG_TAKE
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            off[k] = 0;
+            w00[k] = w01[k] = w10[k] = w11[k] = fw[k] = 0.0f;
+            if (k < K) agg_form_tap_set<KMAX>(a, b, k, p, x, y, off[k], w00[k], w01[k], w10[k], w11[k], fw[k]);
         }
     }
 
@@ -282,7 +340,13 @@ template <int KMAX>
 static int launch_agg_q4(const AggArgs& a, hipStream_t s) {
     const int DQ = a.D / 4, npx = PMN_BLOCK / DQ;
     const dim3 grid((a.h * a.w + npx - 1) / npx, a.B), block(npx * DQ);
-    hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX>), grid, block, 0, s, a);
+    // the cascade's hypothesis counts (8, 16, 32, 64) share the tap sets inside the pixel's lane group; other D % 4 == 0: every thread
+    // forms its own
+    if (DQ == 2) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 2>), grid, block, 0, s, a);
+    else if (DQ == 4) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 4>), grid, block, 0, s, a);
+    else if (DQ == 8) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 8>), grid, block, 0, s, a);
+    else if (DQ == 16) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 0>), grid, block, 0, s, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

@@ -121,8 +121,10 @@ __device__ __forceinline__ float blend_corners(const PmnCorners& c, const float4
 // EXACT: the hypothesis count equals the compile-time bound DT, so every `d < D` test folds away and the unrolled phase-B
 // loop is straight-line code (with run-time guards each item becomes its own basic block and hipcc serialises
 // load -> wait -> compute per item: no memory-level parallelism).
+// (occupancy: the FeatureWeightNet launches run 5 waves per SIMD -- 96 registers; at 98 the stage-1 launch lost 10 % -- the others 4 / 3;
+// 5 waves measured no faster for the known-weights launches)
 template <int C, int G, int MODE, int DT, bool EXACT>
-__global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : 4)) void gather_corr_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == MODE_NEIGHBOR && DT <= 16) ? 5 : 4)) void gather_corr_kernel(const GatherArgs a) {
     constexpr int LPI = C / 4;               // lanes per (pixel, hypothesis) item
     constexpr int NPIX = PMN_BLOCK / LPI;    // pixels per workgroup tile
     constexpr int CG = C / G;                // channels per correlation group (4 or 8)

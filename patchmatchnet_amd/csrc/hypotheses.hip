@@ -167,6 +167,10 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
     const int k0 = -((a.num_sample + 1) / 2);
     const int kc = k0 + a.num_sample / 2;
     const bool from_noise = a.noise != nullptr;
+    // the divisions below are IEEE divisions in hipcc's own fma sequence (pmn_div / pmn_div_by, csrc/pmn_common.hpp: same bits as `/`,
+    // 8 instructions instead of 12, 5 where the divisor is a launch constant); init_hypotheses_kernel keeps the plain operator and
+    // tests/test_hip_parity.py holds both against the oracle
+    const float r48 = pmn_uniform(pmn_rcp_refined(48.0f));
 
     float v[NP2];
 #pragma unroll
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
         for (int j = 0; j < D0T; ++j) u[j] = a.noise[((size_t)b * 48 + j) * hw + p];
 #pragma unroll
         for (int j = 0; j < D0T; ++j) {
-            const float inv = inv_max + (u[j] + (float)j) / 48.0f * (inv_min - inv_max);
-            v[j] = 1.0f / inv;
+            const float inv = inv_max + pmn_div_by(u[j] + (float)j, 48.0f, r48) * (inv_min - inv_max);
+            v[j] = pmn_div(1.0f, inv);
         }
     } else {
         const float dprev =
@@ -188,12 +192,12 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
         if (D0T == 1) {
             v[0] = dprev;
         } else {
-            const float inv_prev = 1.0f / dprev;
+            const float inv_prev = pmn_div(1.0f, dprev);
 #pragma unroll
             for (int j = 0; j < D0T; ++j) {
                 float inv = inv_prev + interval * (float)(k0 + j);
                 inv = fminf(fmaxf(inv, inv_max), inv_min);
-                v[j] = 1.0f / inv;
+                v[j] = pmn_div(1.0f, inv);
             }
         }
     }
@@ -233,14 +237,14 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (from_noise) {
-                        const float inv = inv_max + (c[i][q] + 24.0f) / 48.0f * (inv_min - inv_max);
-                        cc[q] = 1.0f / inv;
+                        const float inv = inv_max + pmn_div_by(c[i][q] + 24.0f, 48.0f, r48) * (inv_min - inv_max);
+                        cc[q] = pmn_div(1.0f, inv);
                     } else if (a.num_sample == 1) {
                         cc[q] = c[i][q];
                     } else {
-                        float inv = 1.0f / c[i][q] + interval * (float)kc;
+                        float inv = pmn_div(1.0f, c[i][q]) + interval * (float)kc;
                         inv = fminf(fmaxf(inv, inv_max), inv_min);
-                        cc[q] = 1.0f / inv;
+                        cc[q] = pmn_div(1.0f, inv);
                     }
                 }
                 v[D0T + k0b + i] = fmaf(cc[3], t[i].w11, fmaf(cc[2], t[i].w10, fmaf(cc[1], t[i].w01, cc[0] * t[i].w00)));
@@ -268,12 +272,12 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
         }
     }
 
-    const float range = inv_min - inv_max;
+    const float range = inv_min - inv_max, rrange = pmn_rcp_refined(range);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         const size_t o = ((size_t)b * D + j) * hw + p;
         a.depth_sample[o] = v[j];
-        a.xnorm[((size_t)b * hw + p) * D + j] = (1.0f / v[j] - inv_max) / range;  // hypothesis-last [B,h,w,D]
+        a.xnorm[((size_t)b * hw + p) * D + j] = pmn_div_by(pmn_div(1.0f, v[j]) - inv_max, range, rrange);  // hypothesis-last [B,h,w,D]
     }
 }
 

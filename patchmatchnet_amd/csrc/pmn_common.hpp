@@ -115,6 +115,9 @@ struct PmnPose {
 // or image sizes -- so for every operand this file divides the sequence below IS the compiler's, bit for bit, at 8 instead of 12
 // instructions, and its first three (the refined reciprocal) are shared by divisions with a common denominator.  The warp has four
 // divisions per (pixel, hypothesis, view): 48 -> 23 instructions (round 4: profiles/r04_ieee_attribution.md).
+__device__ __forceinline__ float pmn_uniform(float v) {  // a wave-uniform value, moved to a scalar register
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 __device__ __forceinline__ float pmn_rcp_refined(float d) {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e = fmaf(-d, r0, 1.0f);
@@ -129,6 +132,8 @@ __device__ __forceinline__ float pmn_div_by(float n, float d, float r) {  // n /
     return fmaf(e3, r, q1);
 }
 
+__device__ __forceinline__ float pmn_div(float n, float d) { return pmn_div_by(n, d, pmn_rcp_refined(d)); }  // n / d, 8 instructions
+
 __device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y, int h, int w) {
 #pragma clang fp contract(off)
     PmnPose q;
@@ -138,10 +143,11 @@ __device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, fl
     q.tx = P[3];
     q.ty = P[7];
     q.tz = P[11];
-    q.cx = (float)(w - 1) / 2.0f;
-    q.cy = (float)(h - 1) / 2.0f;
-    q.rcx = pmn_rcp_refined(q.cx);
-    q.rcy = pmn_rcp_refined(q.cy);
+    // launch constants: held in SGPRs (hipcc leaves a uniform float that came out of the VALU in a vector register per lane)
+    q.cx = pmn_uniform((float)(w - 1) / 2.0f);
+    q.cy = pmn_uniform((float)(h - 1) / 2.0f);
+    q.rcx = pmn_uniform(pmn_rcp_refined(q.cx));
+    q.rcy = pmn_uniform(pmn_rcp_refined(q.cy));
     return q;
 }
 
@@ -172,14 +178,18 @@ __device__ __forceinline__ void pmn_warp_position(const float* __restrict__ P, f
 }
 
 // Neighbour k of pixel (x,y): fixed table offset + learned offset, normalised with (size-1)/2 (get_grid,
-// reference models/patchmatch.py:409-421) but sampled with align_corners=False + border clip.
+// reference models/patchmatch.py:409-421) but sampled with align_corners=False + border clip.  The two divisions by the launch
+// constants (w-1)/2, (h-1)/2 are IEEE divisions in hipcc's own fma sequence (pmn_div_by: same bits as `X / c`, 5 instructions each
+// with the refined reciprocal hoisted out of the neighbour loop, instead of 12).
 __device__ __forceinline__ void pmn_neighbor_position(float x, float y, int dy, int dx, float offx, float offy,
                                                       int h, int w, float& ix, float& iy) {
 #pragma clang fp contract(off)
+    const float cx = pmn_uniform((float)(w - 1) / 2.0f), cy = pmn_uniform((float)(h - 1) / 2.0f);
+    const float rcx = pmn_uniform(pmn_rcp_refined(cx)), rcy = pmn_uniform(pmn_rcp_refined(cy));  // loop-invariant, in SGPRs
     float X = x + ((float)dx + offx);
     float Y = y + ((float)dy + offy);
-    float xn = X / ((float)(w - 1) / 2.0f) - 1.0f;
-    float yn = Y / ((float)(h - 1) / 2.0f) - 1.0f;
+    float xn = pmn_div_by(X, cx, rcx) - 1.0f;
+    float yn = pmn_div_by(Y, cy, rcy) - 1.0f;
     ix = fminf(fmaxf(pmn_unnorm_noalign(xn, w), 0.0f), (float)(w - 1));
     iy = fminf(fmaxf(pmn_unnorm_noalign(yn, h), 0.0f), (float)(h - 1));
 }

@@ -44,7 +44,11 @@ def main():
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--flat", action="store_true", help="all hypotheses of a pixel equal: ~100%% L1 hits (upper bound probe)")
+    ap.add_argument("--lib", default=None, help="A/B: load this build of libpmn_hip.so instead of the tree's")
     args = ap.parse_args()
+    if args.lib:
+        from patchmatchnet_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops, params
     dev = "cuda:0"
