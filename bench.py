@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent samples in flight per GPU: one HIP stream + one HIP-graph replay slot each (1 = one stream)")
+    ap.add_argument("--copy-inputs", action="store_true",
+                    help="graph replay reads copies of all six images in the slot's static buffers (rounds 2-4) instead of the samples in place")
     ap.add_argument("--eager", action="store_true",
                     help="issue every kernel from Python on one stream (the round-1 mode) instead of replaying HIP graphs")
     ap.add_argument("--roofline-steps", type=int, default=24,
@@ -389,7 +391,9 @@ def main():
     # The kernels of a forward are bound by different units (vector-memory pipe for the gathers, matrix cores for the
     # convolutions, VALU for the stem / aggregation), so two forwards sharing the CUs finish sooner than one after the other;
     # the graph takes the ~3.5 ms of Python launch work per forward off the critical path.  Every step runs the whole forward on
-    # its own inputs (copied into the slot's static buffers inside the timed region).
+    # its own inputs, read where the samples sit in HBM (graph.GraphedForward(inputs_in_place=True): FeatureNet finds the six images
+    # through a device table of addresses rewritten per step; the cameras, depth range and the reference image Refinement reads are
+    # copied into the slot's static buffers inside the timed region; --copy-inputs = all six images copied, rounds 2-4's mode).
     S = 1 if args.eager else max(args.in_flight, 1)
     main_stream = torch.cuda.current_stream(device)
     with torch.no_grad():
@@ -455,7 +459,7 @@ def main():
             timed region, so that every rank then takes the same path)."""
             from patchmatchnet_amd.graph import GraphedForward
             streams = [torch.cuda.Stream(device) for _ in range(S)]
-            slots = [GraphedForward(model) for _ in range(S)]
+            slots = [GraphedForward(model, inputs_in_place=not args.copy_inputs) for _ in range(S)]
 
             def replay(i):
                 k, s = i % S, samples[i % len(samples)]
@@ -570,7 +574,9 @@ def main():
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
                        "untimed_steps_before_the_timed_region": max(args.warmup, S if not args.eager else 0) + extra_warmup[0],
                        "in_flight": S, "launch": launch_note or ("python, one stream" if args.eager else
-                       f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU")},
+                       f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU; images "
+                       + ("copied into the slot's static buffers" if args.copy_inputs else
+                          "read in place through a device table of addresses (pmn_stem_f16s_views)"))},
             "steady_state": None if steady is None else {
                 "steps": steady[0], "seconds": round(steady[1], 3), "value": round(world * steady[0] / steady[1], 2),
                 "note": "the timed region's loop repeated for ~%.0f s in the same mode (not the contract's K steps)" % args.steady_seconds},

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 17
+#define PMN_ABI_VERSION 18
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -247,6 +247,13 @@ int pmn_stem(const float *img, const float *w0, const float *s0, const float *w1
  * as MFMA rows.  w1a DEVICE float16 [3][2][64][8] (patchmatchnet_amd/params.py pack_stem_conv1_f16s); everything else as pmn_stem. */
 int pmn_stem_f16s(const float *img, const float *w0, const float *s0, const void *w1a, const float *s1, float *out, int N, int H,
                   int W, void *stream);
+
+/* pmn_stem_f16s for `views` separately allocated images of one size (reference models/net.py:203-208: FeatureNet runs per image of
+ * the `images` list): img_table DEVICE array of `views` addresses, entry v = a dense [B,3,H,W] float32 tensor, every address 16-byte
+ * aligned (caller's contract); out [views*B,H,W,8] view-major.  The table is read when the kernel runs: a captured launch follows
+ * whatever the table holds at replay time, so a HIP graph reads each sample's images in place (patchmatchnet_amd/graph.py). */
+int pmn_stem_f16s_views(const float *const *img_table, int views, const float *w0, const float *s0, const void *w1a,
+                        const float *s1, float *out, int B, int H, int W, void *stream);
 
 /* Stand-alone differentiable_warping (reference models/module.py:130-181) for API completeness and unit
  * parity: src_nchw [B,C,hs,ws], rel_proj [B,4,4], depth [B,D,h,w] -> warped [B,C,D,h,w].  Not on the fast path. */

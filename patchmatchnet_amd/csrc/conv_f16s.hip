@@ -363,7 +363,8 @@ template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
                                                           const float* __restrict__ s0, const f16x8* __restrict__ w1A,
                                                           const float* __restrict__ s1, float* __restrict__ out, const int N,
-                                                          const int H, const int W) {
+                                                          const int H, const int W, const float* const* __restrict__ img_tab,
+                                                          const int BV) {
     constexpr int TS = 16, IW = TS + 4, XS = 24, MW = TS + 2, MRP = 18, MROWS = 18, NTHR = 256;
     __shared__ float4 xin4[3 * IW * (XS / 4)];
     __shared__ float4 mid4[2 * MROWS * MRP];  // two planes of 18 x 18 pixel slots x 8 halves (16 B)
@@ -378,6 +379,9 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
     const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
     const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
     const int oy0 = (tr / tiles_x) * TS, ox0 = (tr % tiles_x) * TS;
+    // image n of the launch: a slice of one [N,3,H,W] tensor, or -- pmn_stem_f16s_views -- batch element n % BV of the view n / BV
+    // whose [BV,3,H,W] tensor sits wherever the device table says (wave-uniform: one scalar load)
+    if (img_tab) img = img_tab[n / BV] + (ptrdiff_t)((n % BV) - n) * 3 * H * W;  // (the indexing below adds n * 3 * H * W)
 
     // conv1's weights (A operands of the three k-steps, hi | lo): six 1 KB loads per wave, in flight across the staging below
     f16x8 wa[3][2];
@@ -513,10 +517,31 @@ extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0,
     // aligned float4 staging needs 16-byte aligned image rows: W % 4 == 0 and a 16-byte aligned base
     if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0)
         hipLaunchKernelGGL(stem_f16s_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
-                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
     else
         hipLaunchKernelGGL(stem_f16s_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
-                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W);
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// The same for `views` separately allocated images of one size: img_table DEVICE array of `views` addresses, entry v = a dense
+// [B,3,H,W] float32 tensor, every address 16-byte aligned (the caller's contract: the library cannot see the entries when it
+// launches); out [views*B,H,W,8] view-major, as the stacked call would write it.  The table is read when the kernel RUNS: a captured
+// launch (HIP graph) follows whatever the table holds at replay time -- patchmatchnet_amd/graph.py reads a sample's images where
+// the caller left them instead of copying them into static buffers (6 x 23 MB per 1600x1200 sample).
+extern "C" int pmn_stem_f16s_views(const float* const* img_table, int views, const float* w0, const float* s0, const void* w1a,
+                                   const float* s1, float* out, int B, int H, int W, void* stream) {
+    if (!img_table || !w0 || !s0 || !w1a || !s1 || !out || views < 1 || B < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    constexpr int TS = 16;
+    const int N = views * B;
+    const int blocks = N * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+    if (W % 4 == 0)
+        hipLaunchKernelGGL(stem_f16s_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
+    else
+        hipLaunchKernelGGL(stem_f16s_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+                           reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

@@ -32,10 +32,17 @@ class GraphedForward:
 
     The returned tensors are the graph's static outputs: consume (copy) them before the next call with the same signature
     overwrites them.  Inputs whose sizes PatchmatchNet.forward would adjust (height / width not multiples of 8, reference
-    net.py:304-318) run eagerly -- that path resizes the images and rewrites the caller's intrinsics in place."""
+    net.py:304-318) run eagerly -- that path resizes the images and rewrites the caller's intrinsics in place.
 
-    def __init__(self, model, max_graphs: int = 8) -> None:
-        self.model, self.max_graphs = model, max_graphs
+    ``inputs_in_place=True``: the replayed FeatureNet reads the caller's image tensors WHERE THEY ARE, through a device table of
+    addresses rewritten per call (pmn_stem_f16s_views), instead of from copies in the slot's static buffers (six 23 MB copies per
+    1600x1200 sample; only the reference image, which Refinement reads, is still copied).  The caller then has to leave the images
+    alone until the replay has run -- not only until this call returns: for tensors that live as long as the scan (bench.py's resident
+    samples) that is free; a pipeline that recycles its upload buffers keeps the default.  An image the kernel cannot read in place
+    (not dense float32, or not 16-byte aligned) is copied into the slot and the table points there."""
+
+    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
+        self.model, self.max_graphs, self.inputs_in_place = model, max_graphs, inputs_in_place
         self.cache: Dict[Tuple, Tuple] = {}
         self.replays = self.captures = self.evictions = 0
 
@@ -52,16 +59,31 @@ class GraphedForward:
         return (tuple(tuple(i.shape) for i in images), cls._alias_pattern(images), tuple(intrinsics.shape), feat,
                 features is not None and cls._table_ok(features))
 
+    def _images_in_place(self, features) -> bool:
+        feature = getattr(self.model, "feature", None)
+        return bool(self.inputs_in_place and features is None and getattr(self.model, "hip_feature_net", False)
+                    and feature is not None and feature.f16_split)
+
     def _capture(self, images, intrinsics, extrinsics, depth_min, depth_max, features):
         dev = intrinsics.device
         pattern = self._alias_pattern(images)
-        bufs = [torch.empty_like(im) if pattern[i] == i else None for i, im in enumerate(images)]
+        in_place = self._images_in_place(features)
+        # (in place: only the reference image gets a static buffer up front; another view gets one the first time it cannot be read
+        # where it is, _fill)
+        bufs = [torch.empty_like(im) if pattern[i] == i and not (in_place and i) else None for i, im in enumerate(images)]
         static = dict(images=[bufs[pattern[i]] for i in range(len(images))], intrinsics=torch.empty_like(intrinsics),
                       extrinsics=torch.empty_like(extrinsics), depth_min=torch.empty_like(depth_min),
                       depth_max=torch.empty_like(depth_max),
                       noise=torch.empty((images[0].shape[0], 48, images[0].shape[2] // 8, images[0].shape[3] // 8),
                                         dtype=torch.float32, device=dev),
                       features=None, features_nhwc=None)
+        if in_place:
+            from . import ops
+            static["images"] = [bufs[0]] * len(images)  # shapes for the forward; FeatureNet reads through the table, Refinement entry 0
+            static["image_bufs"] = bufs
+            static["image_table"] = ops.SourceTable(torch.zeros(len(images), dtype=torch.int64, device=dev),
+                                                    (len(images),) + tuple(images[0].shape))
+            static["table_host"] = []
         if features is not None and self._table_ok(features):
             # injected pyramids that are channels-last maps of their own (eval.py's encode-once path): only the REFERENCE view's
             # pyramid is copied into static buffers (offset heads, FeatureWeightNet and the cascade read it); the SOURCE views stay
@@ -95,7 +117,8 @@ class GraphedForward:
         def run():
             return self.model(list(static["images"]), static["intrinsics"], static["extrinsics"], static["depth_min"],
                               static["depth_max"], features=static["features"], features_nhwc=static["features_nhwc"],
-                              noise=static["noise"], source_tables=static.get("tables"), ref_nhwc_maps=static.get("ref_nhwc"))
+                              noise=static["noise"], source_tables=static.get("tables"), ref_nhwc_maps=static.get("ref_nhwc"),
+                              image_table=static.get("image_table"))
 
         rng = torch.cuda.get_rng_state(dev)  # warm-up and capture must not advance the caller's random stream
         self._draw(static)
@@ -136,12 +159,48 @@ class GraphedForward:
         torch.rand(size=tuple(static["noise"].shape), out=static["noise"])
 
     @staticmethod
-    def _fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
-        done = set()
-        for dst, src in zip(static["images"], images):  # aliased inputs share one static buffer: copied once
-            if dst.data_ptr() not in done and dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
-            done.add(dst.data_ptr())
+    def _stage_addresses(static, rows) -> None:
+        """rows: [(device int64 table, [addresses])].  Written through a ring of pinned host buffers, each guarded by an event (the
+        copy is asynchronous: the buffer must not be rewritten before it has been read)."""
+        ring = static["table_host"]
+        total = sum(len(a) for _, a in rows)
+        k = static["turn"] = (static.get("turn", -1) + 1) % 8
+        if k >= len(ring):
+            ring.append([torch.empty(total, dtype=torch.int64).pin_memory(), None])
+        host, ev = ring[k]
+        if ev is not None:
+            ev.synchronize()  # eight samples back: long done
+        o = 0
+        for table, addrs in rows:
+            for j, a in enumerate(addrs):
+                host[o + j] = a
+            table.copy_(host[o:o + len(addrs)], non_blocking=True)
+            o += len(addrs)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(static["intrinsics"].device))
+        ring[k][1] = ev
+
+    @classmethod
+    def _fill(cls, static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
+        if "image_table" in static:
+            from . import ops
+            bufs, addrs = static["image_bufs"], []
+            for i, im in enumerate(images):
+                if i == 0 or not ops.SourceTable.image_in_place(im):
+                    if bufs[i] is None:
+                        bufs[i] = torch.empty(tuple(images[0].shape), dtype=torch.float32, device=static["intrinsics"].device)
+                    if bufs[i].data_ptr() != im.data_ptr():
+                        bufs[i].copy_(im, non_blocking=True)
+                    addrs.append(bufs[i].data_ptr())
+                else:
+                    addrs.append(im.data_ptr())
+            cls._stage_addresses(static, [(static["image_table"].table, addrs)])
+        else:
+            done = set()
+            for dst, src in zip(static["images"], images):  # aliased inputs share one static buffer: copied once
+                if dst.data_ptr() not in done and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+                done.add(dst.data_ptr())
         static["intrinsics"].copy_(intrinsics, non_blocking=True)
         static["extrinsics"].copy_(extrinsics, non_blocking=True)
         static["depth_min"].copy_(depth_min, non_blocking=True)
@@ -150,22 +209,9 @@ class GraphedForward:
             for s, t in features[0].items():
                 static["features"][0][s].copy_(t, non_blocking=True)
             stages = sorted(static["tables"])
-            n_src = len(features) - 1
-            ring = static["table_host"]
-            k = static["turn"] = (static.get("turn", -1) + 1) % 8
-            if k >= len(ring):
-                ring.append([torch.empty(len(stages) * n_src, dtype=torch.int64).pin_memory(), None])
-            host, ev = ring[k]
-            if ev is not None:
-                ev.synchronize()  # eight samples back: long done
-            for i, s in enumerate(stages):
-                for v in range(n_src):
-                    host[i * n_src + v] = features[1 + v][s].permute(0, 2, 3, 1).data_ptr()
-            for i, s in enumerate(stages):
-                static["tables"][s].table.copy_(host[i * n_src:(i + 1) * n_src], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(static["intrinsics"].device))
-            ring[k][1] = ev
+            cls._stage_addresses(static, [(static["tables"][s].table,
+                                           [features[1 + v][s].permute(0, 2, 3, 1).data_ptr() for v in range(len(features) - 1)])
+                                          for s in stages])
         elif features is not None:
             for dst, src in zip(static["features"], features):
                 for s, t in src.items():

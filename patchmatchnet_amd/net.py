@@ -124,15 +124,22 @@ class FeatureNet(nn.Module):
             self._pack, self._pack_key = pk, key
         return self._pack
 
-    def forward_hip(self, x) -> Dict[int, torch.Tensor]:
+    def forward_hip(self, x, image_table: Optional["ops.SourceTable"] = None) -> Dict[int, torch.Tensor]:
         """x [N,3,H,W], or a list of same-size [B,3,H,W] images (stacked view-major without a torch.cat copy: the first
         layer writes each image's output into its slice) -> {3: [N,H/8,W/8,64], 2: [N,H/4,W/4,32], 1: [N,H/2,W/2,16]}
-        CHANNELS-LAST (inference only)."""
+        CHANNELS-LAST (inference only).  ``image_table`` (ops.SourceTable of shape (views, B, 3, H, W)): the images are read through
+        a device table of addresses instead of ``x`` (one launch; graph.GraphedForward(inputs_in_place=True))."""
         pk = self._packed()
         imgs = list(x) if isinstance(x, (list, tuple)) else [x]
         B, _, H, W = imgs[0].shape
-        t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
-        for i, im in enumerate(imgs):  # conv0 + conv1 fused (pmn_stem_f16s: conv1 on the fp16 matrix cores; pmn_stem: all fp32 VALU)
+        in_place = image_table is not None
+        if in_place and not (self.f16_split and "conv1_f16s" in pk):
+            raise PmnError("image_table: only the fp16-split stem (FeatureNet.f16_split, weights inside its domain) reads images in place")
+        if in_place:
+            t = ops.stem_f16s_views(image_table, *pk["conv0"], *pk["conv1_f16s"])
+        else:
+            t = torch.empty((B * len(imgs), H, W, 8), dtype=torch.float32, device=imgs[0].device)
+        for i, im in enumerate(() if in_place else imgs):  # conv0 + conv1 fused (pmn_stem_f16s: conv1 on the fp16 matrix cores; pmn_stem: all fp32 VALU)
             if self.f16_split and "conv1_f16s" in pk:
                 ops.stem_f16s(im.contiguous(), *pk["conv0"], *pk["conv1_f16s"], out=t[i * B:(i + 1) * B])
             else:
@@ -308,13 +315,16 @@ class PatchmatchNet(nn.Module):
             state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def extract_features(self, images: List[torch.Tensor], stacked: Optional[dict] = None) -> List[Dict[int, torch.Tensor]]:
+    def extract_features(self, images: List[torch.Tensor], stacked: Optional[dict] = None,
+                         image_table: Optional["ops.SourceTable"] = None) -> List[Dict[int, torch.Tensor]]:
         """Per-view feature pyramids.  ``stacked`` (a dict) additionally receives {stage: [V*B,C,h,w]} when all views
         went through FeatureNet as one batch (view-major), so the caller can change layout in one pass."""
         same = all(im.shape == images[0].shape for im in images)
         B = images[0].shape[0]
+        if image_table is not None and not (self.hip_feature_net and same and images[0].is_cuda and self.feature.f16_split):
+            raise PmnError("image_table needs the HIP FeatureNet (f16_split) and same-size images on a ROCm device")
         if self.hip_feature_net and same and images[0].is_cuda:
-            f = self.feature.forward_hip(images)
+            f = self.feature.forward_hip(images, image_table=image_table)
             if stacked is not None:
                 stacked.update({("nhwc", s): t for s, t in f.items()})
             # per-view NCHW-shaped views over the channels-last storage (no copy)
@@ -333,7 +343,7 @@ class PatchmatchNet(nn.Module):
                 depth_min: torch.Tensor, depth_max: torch.Tensor, noise: Optional[torch.Tensor] = None,
                 features: Optional[List[Dict[int, torch.Tensor]]] = None, debug: Optional[dict] = None,
                 features_nhwc: Optional[Dict[int, torch.Tensor]] = None, source_tables: Optional[Dict[int, "ops.SourceTable"]] = None,
-                ref_nhwc_maps: Optional[Dict[int, torch.Tensor]] = None
+                ref_nhwc_maps: Optional[Dict[int, torch.Tensor]] = None, image_table: Optional["ops.SourceTable"] = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Dict[int, List[torch.Tensor]]]:
         """Reference arguments (images: N x [B,3,H,W]; intrinsics [B,N,3,3]; extrinsics [B,N,4,4]; depth_min/max [B]).
 
@@ -342,7 +352,9 @@ class PatchmatchNet(nn.Module):
         in one channels-last buffer per stage -- what ``features[v][stage]`` are views of -- so that the kernels read them in place
         instead of stacking the source views into a buffer of their own; or ``source_tables`` {stage: ops.SourceTable} +
         ``ref_nhwc_maps`` {stage: [B,h,w,C]}: the source views stay wherever they are and the kernels find them through a device
-        table of addresses, pmn_warp_correlate_views), ``debug`` (dict) collects per-stage intermediates.
+        table of addresses, pmn_warp_correlate_views), ``image_table`` (ops.SourceTable, shape (N, B, 3, H, W)): FeatureNet reads the
+        images through a device table of addresses (pmn_stem_f16s_views) -- ``images`` then only supplies shapes and, entry 0, the
+        reference image Refinement reads --, ``debug`` (dict) collects per-stage intermediates.
         Returns (depth [B,1,H,W], photometric confidence [B,H,W] (empty in training mode), {stage: [depths]})."""
         assert len(images) == intrinsics.size()[1], "Different number of images and intrinsic matrices"
         assert len(images) == extrinsics.size()[1], "Different number of images and extrinsic matrices"
@@ -355,7 +367,7 @@ class PatchmatchNet(nn.Module):
 
         stacked: Dict[int, torch.Tensor] = {}
         if features is None:
-            features = self.extract_features(images, stacked)
+            features = self.extract_features(images, stacked, image_table)
         elif features_nhwc is not None:
             stacked.update({("nhwc", st): t for st, t in features_nhwc.items()})
         ref_feature, src_features = features[0], features[1:]

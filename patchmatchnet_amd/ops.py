@@ -262,6 +262,11 @@ class SourceTable:
         self.table, self.shape, self.device = table, tuple(int(x) for x in shape), table.device
 
     @staticmethod
+    def image_in_place(im: torch.Tensor) -> bool:
+        """True when pmn_stem_f16s_views can read this [B,3,H,W] image where it is (dense float32, 16-byte aligned)."""
+        return bool(im.is_cuda and im.dtype == torch.float32 and im.is_contiguous() and im.data_ptr() % 16 == 0)
+
+    @staticmethod
     def addresses(maps) -> list:
         """data_ptr of every view's map after checking it is a dense channels-last [B,hs,ws,C] float32 device tensor."""
         out = []
@@ -730,6 +735,25 @@ def stem_f16s(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1a: torch.
     with torch.cuda.device(img.device):
         check(_lib.lib().pmn_stem_f16s(img.data_ptr(), w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(), out.data_ptr(),
                                        N, H, W, _stream(img)), "pmn_stem_f16s")
+    return out
+
+
+def stem_f16s_views(images: "SourceTable", w0: torch.Tensor, s0: torch.Tensor, w1a: torch.Tensor, s1: torch.Tensor) -> torch.Tensor:
+    """pmn_stem_f16s_views: the fused stem over ``views`` separately allocated [B,3,H,W] images found through a device table of
+    addresses (``images``: a SourceTable with shape (views, B, 3, H, W)) -> [views*B,H,W,8] view-major.  A captured launch reads
+    whatever the table holds at replay time (graph.GraphedForward(inputs_in_place=True))."""
+    for n_, t_ in (("w0", w0), ("s0", s0), ("s1", s1)):
+        _dev(t_, n_)
+    if not isinstance(images, SourceTable) or len(images.shape) != 5 or images.shape[2] != 3:
+        raise PmnError("stem_f16s_views: a SourceTable of shape (views, B, 3, H, W)")
+    if not isinstance(w1a, torch.Tensor) or not w1a.is_cuda or w1a.dtype != torch.float16 or tuple(w1a.shape) != (3, 2, 64, 8) \
+            or not w1a.is_contiguous() or tuple(w0.shape) != (3, 3, 3, 8):
+        raise PmnError("stem_f16s_views: 3->8 conv0 weights and the float16 [3,2,64,8] tensor of params.pack_stem_conv1_f16s")
+    V, B, _, H, W = images.shape
+    out = torch.empty((V * B, H, W, 8), dtype=torch.float32, device=images.device)
+    with torch.cuda.device(images.device):
+        check(_lib.lib().pmn_stem_f16s_views(images.table.data_ptr(), V, w0.data_ptr(), s0.data_ptr(), w1a.data_ptr(), s1.data_ptr(),
+                                             out.data_ptr(), B, H, W, _stream(out)), "pmn_stem_f16s_views")
     return out
 
 

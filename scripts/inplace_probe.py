@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """What do the per-sample input copies of a graph replay cost?  bench.py's timed loop (3 samples in flight, one HIP-graph slot each)
-A: as bench.py runs it -- every step copies its six images (138 MB) into the slot's static buffers;
-B: upper bound of reading the inputs in place -- the slot is fed its own static image buffers, so GraphedForward._fill skips them.
+A: GraphedForward(model) -- every step copies its six images (138 MB) into the slot's static buffers (rounds 2-4);
+B: GraphedForward(model, inputs_in_place=True) -- FeatureNet reads the samples where they are (pmn_stem_f16s_views), one image copied.
 Alternates A B A B on one box.   python scripts/inplace_probe.py [--seconds 3]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,22 +23,20 @@ model = model.to(dev).eval()
 samples = bench.make_samples(12, 6, 1200, 1600, dev, 0)
 S = a.in_flight
 streams = [torch.cuda.Stream(dev) for _ in range(S)]
-slots = [GraphedForward(model) for _ in range(S)]
+slots = {False: [GraphedForward(model) for _ in range(S)], True: [GraphedForward(model, inputs_in_place=True) for _ in range(S)]}
 main = torch.cuda.current_stream(dev)
 
 def replay(i, in_place):
     k, s = i % S, samples[i % len(samples)]
     with torch.cuda.stream(streams[k]):
-        imgs = [im for im in s["images"]]
-        if in_place and slots[k].cache:
-            imgs = list(next(iter(slots[k].cache.values()))[1]["images"])
-        return slots[k](imgs, s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
+        return slots[in_place][k]([im for im in s["images"]], s["intrinsics"], s["extrinsics"], s["depth_min"], s["depth_max"])
 
 with torch.no_grad():
     for st in streams:
         st.wait_stream(main)
     for i in range(2 * S):
         replay(i, False)
+        replay(i, True)
     torch.cuda.synchronize()
     def run(in_place, seconds):
         torch.cuda.synchronize()
@@ -54,4 +52,4 @@ with torch.no_grad():
     for r in range(3):
         va = run(False, a.seconds); vb = run(True, a.seconds)
         print(f"round {r}: A copies {va:7.2f} depth-maps/s   B in place {vb:7.2f}   B/A {vb / va:.4f}", flush=True)
-    print("captures per slot:", [s.captures for s in slots])
+    print("captures per slot:", [s.captures for m in slots.values() for s in m])
