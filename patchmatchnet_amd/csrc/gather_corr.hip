@@ -27,6 +27,8 @@
 //                   the weighted sums in its own registers.
 //     The [C,D,h,w] warped volume and the per-view [G,D,h,w] similarity never touch HBM.
 //   * no MFMA: ~10 flop per gathered float, no dense contraction worth a matrix core (the MLPs are 16x8 / 8x16).
+#include <type_traits>
+
 #include "gather_common.hpp"
 
 // Broadcast `v` from lane SL of every aligned group of LPI lanes (SL compile-time): DPP quad_perm for 4-lane groups,
@@ -461,20 +463,41 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
         if (MODE == MODE_NEIGHBOR) {
             if (!okA) return;
             // scalar MLP, NI items per call: on this launch the packed-pair form (mlp_items) measured 7 % SLOWER at stage 1
-            // (137.7 vs 128.5 us, same box) -- and re-pairing a float [NIT][G] array sent it through scratch
+            // (137.7 vs 128.5 us, same box) -- and re-pairing a float [NIT][G] array sent it through scratch.
+            // Only the items some lane of this WAVE owns are evaluated: the hypothesis bound DT = 16 / 32 covers K = 9 / 17
+            // neighbours, and a thread's items are d = dA0 + j * DSTEP -- at K = 9 that is 2.25 of the 4 (C = 16), 1.25 of the 2
+            // (C = 32), 0.56 of the 1 (C = 64) rounds the clamped form evaluated for every thread, and the MLP (200-264 FMAs per
+            // item) was 57 % of this kernel's instructions.  The count is wave-uniform (dA0 = tid / NPIX), so the switch is a
+            // scalar branch; every evaluated item is computed exactly as before.
+            const int wave_d0 = __builtin_amdgcn_readfirstlane((tid & ~63) / NPIX);  // smallest dA0 of this wave
+            const int nvw = wave_d0 < D ? (D - wave_d0 + DSTEP - 1) / DSTEP : 0;     // items its lanes own: j < nvw
             float o[NIT];
 #pragma unroll
+            for (int j = 0; j < NIT; ++j) o[j] = 0.0f;
+#pragma unroll
             for (int c = 0; c < NIT / NI; ++c) {
-                float xc[NI][G], oc[NI];
+                auto run = [&](auto nv_tag) {
+                    constexpr int NV = decltype(nv_tag)::value;
+                    float xc[NV][G], oc[NV];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
+                    for (int i = 0; i < NV; ++i) {
+                        const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                        for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                    }
+                    mlp_from_lds<G, NV>(wlds_a, xc, oc);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) o[c * NI + i] = oc[i];
+                };
+                const int nvc = min(max(nvw - c * NI, 0), NI);
+                static_assert(NI <= 4, "switch below");
+                switch (nvc) {
+                    case 1: run(std::integral_constant<int, 1>{}); break;
+                    case 2: if constexpr (NI >= 2) run(std::integral_constant<int, 2>{}); break;
+                    case 3: if constexpr (NI >= 3) run(std::integral_constant<int, 3>{}); break;
+                    case 4: if constexpr (NI >= 4) run(std::integral_constant<int, 4>{}); break;
+                    default: break;
                 }
-                mlp_from_lds<G, NI>(wlds_a, xc, oc);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) o[c * NI + i] = oc[i];
             }
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {

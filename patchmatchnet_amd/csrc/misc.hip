@@ -68,11 +68,39 @@ __global__ __launch_bounds__(PMN_BLOCK) void confidence_kernel(const float* __re
     if (dindex) dindex[(size_t)b * hw + (size_t)y * w + x] = idx;
 }
 
+// The cascade's own case, H = 2h and W = 2w (the nearest resize of net.py:298 then maps output (Y, X) onto (Y >> 1, X >> 1) exactly):
+// one thread per SOURCE pixel evaluates the index and the window sum once and writes its 2 x 2 outputs as two 8-byte stores -- the
+// general kernel evaluated them in each of the four output threads (12 strided reads and the regression per output pixel).
+__global__ __launch_bounds__(PMN_BLOCK) void confidence2x_kernel(const float* __restrict__ score, int D, int h, int w,
+                                                                float* __restrict__ conf, int* __restrict__ dindex) {
+#pragma clang fp contract(off)
+    const int q = blockIdx.x * PMN_BLOCK + threadIdx.x, b = blockIdx.y;
+    if (q >= h * w) return;
+    const int y = q / w, x = q - y * w;
+    const size_t hw = (size_t)h * w;
+    const float* sp = score + (size_t)b * D * hw + q;
+    float idxf = 0.0f;
+    for (int d = 0; d < D; ++d) idxf = idxf + sp[d * hw] * (float)d;
+    int idx = (int)idxf;
+    idx = min(max(idx, 0), D - 1);
+    float s = 0.0f;
+    for (int j = idx - 1; j <= idx + 2; ++j) s = s + ((j >= 0 && j < D) ? sp[j * hw] : 0.0f);
+    s = s / 4.0f * 4.0f;
+    float* o = conf + (size_t)b * 4 * hw + (size_t)(2 * y) * (2 * w) + 2 * x;
+    *reinterpret_cast<float2*>(o) = make_float2(s, s);
+    *reinterpret_cast<float2*>(o + 2 * w) = make_float2(s, s);
+    if (dindex) dindex[(size_t)b * hw + q] = idx;
+}
+
 extern "C" int pmn_confidence(const float* score, int B, int D, int h, int w, int H, int W, float* confidence_out,
                               int* depth_index_out, void* stream) {
     if (!score || !confidence_out || B < 1 || D < 1 || h < 1 || w < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
-    hipLaunchKernelGGL(confidence_kernel, dim3((H * W + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
-                       (hipStream_t)stream, score, D, h, w, H, W, confidence_out, depth_index_out);
+    if (H == 2 * h && W == 2 * w && (reinterpret_cast<uintptr_t>(confidence_out) & 7) == 0)
+        hipLaunchKernelGGL(confidence2x_kernel, dim3((h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+                           (hipStream_t)stream, score, D, h, w, confidence_out, depth_index_out);
+    else
+        hipLaunchKernelGGL(confidence_kernel, dim3((H * W + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+                           (hipStream_t)stream, score, D, h, w, H, W, confidence_out, depth_index_out);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

@@ -978,3 +978,25 @@ def test_warp_correlate_views_reads_the_sources_in_place():
         b = P.ops.warp_correlate(ref, table, rel, depth, vw, 0, mlp(1), None if vw is not None else mlp(2), G, want_similarity=True)
         torch.cuda.synchronize()
         assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[1], b[1])
+
+
+def test_confidence_2x_path_equals_the_general_kernel():
+    """pmn_confidence at H = 2h, W = 2w (one thread per source pixel, 2 x 2 outputs each) against the general nearest-resize kernel,
+    which the same call takes when the output is not 8-byte aligned; and the general kernel at a non-2x size stays reachable."""
+    P = _gpu()
+    from patchmatchnet_amd import _lib, ops
+    g = torch.Generator().manual_seed(8)
+    for (B, D, h, w) in ((1, 8, 37, 50), (2, 8, 16, 24), (1, 16, 9, 11)):
+        score = torch.softmax(4 * torch.randn(B, D, h, w, generator=g), 1).to(DEV).contiguous()
+        fast, idx_fast = ops.confidence(score, 2 * h, 2 * w, want_index=True)
+        buf = torch.empty(B * 4 * h * w + 1, device=DEV)
+        slow = buf[1:].view(B, 2 * h, 2 * w)
+        assert slow.data_ptr() % 8 == 4
+        idx_slow = torch.empty(B, h, w, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().pmn_confidence(score.data_ptr(), B, D, h, w, 2 * h, 2 * w, slow.data_ptr(), idx_slow.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "pmn_confidence")
+        torch.cuda.synchronize()
+        assert torch.equal(fast, slow) and torch.equal(idx_fast, idx_slow)
+        assert bool((fast[:, ::2, ::2] == fast[:, 1::2, 1::2]).all())
+        odd, _ = ops.confidence(score, 2 * h + 3, 2 * w - 1)
+        assert odd.shape == (B, 2 * h + 3, 2 * w - 1) and bool(torch.isfinite(odd).all())
