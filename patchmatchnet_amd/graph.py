@@ -60,9 +60,14 @@ class GraphedForward:
                 features is not None and cls._table_ok(features))
 
     def _images_in_place(self, features) -> bool:
+        """The replayed FeatureNet can read the images through a table: asked for, FeatureNet is part of the graph, and its stem is the
+        fp16-split kernel (pmn_stem_f16s_views; a checkpoint outside the split's domain falls back to the fp32 stem, which has no
+        table form -- then the images are copied as usual)."""
         feature = getattr(self.model, "feature", None)
-        return bool(self.inputs_in_place and features is None and getattr(self.model, "hip_feature_net", False)
-                    and feature is not None and feature.f16_split)
+        if not (self.inputs_in_place and features is None and getattr(self.model, "hip_feature_net", False)
+                and feature is not None and feature.f16_split):
+            return False
+        return "conv1_f16s" in feature._packed()
 
     def _capture(self, images, intrinsics, extrinsics, depth_min, depth_max, features):
         dev = intrinsics.device
