@@ -23,6 +23,9 @@ Outputs (committed):
                            confidence, every stage / iteration depth, stage-3 view weights and the integer confidence index,
                            FREE-RUNNING from the images (``--only scene``; ~15 s of CPU).  Inputs regenerate from the seeds;
                            ``scene_digest`` pins them.
+  cascade_resized_100x130.npz  a 100x130 sample (not multiples of 8): the reference stretches the images to 96x128, rescales the
+                           intrinsics in place (models/net.py:304-318), and returns depth (bilinear) and confidence (nearest) at
+                           100x130 -- its final depth, confidence, stage depths and the intrinsics it left behind (``--only resized``).
 """
 import os
 import sys
@@ -154,6 +157,30 @@ def dump_mixed(path, model):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def resized_inputs():
+    """Seeded 100x130 sample of the synthetic rig (sizes the reference has to adjust: 100 -> 96, 130 -> 128)."""
+    import synth
+    H, W = 100, 130
+    imgs = synth.synthetic_images(3, H, W)
+    intr, extr = synth.synthetic_cameras(3, H, W)
+    noise = torch.rand(1, 48, 12, 16, generator=torch.Generator().manual_seed(55))
+    return imgs, intr, extr, np.array([425.0], np.float32), np.array([935.0], np.float32), noise
+
+
+def dump_resized(path, model):
+    """The reference on a sample whose size is not a multiple of 8 (adjust_image_dims, models/net.py:304-318)."""
+    imgs, intr, extr, dmin, dmax, noise = resized_inputs()
+    K = torch.from_numpy(intr).clone()
+    depth, conf, dpm, tr = refutil.trace_reference_forward(
+        model, [i.clone() for i in imgs], K, torch.from_numpy(extr).clone(), torch.from_numpy(dmin), torch.from_numpy(dmax), noise)
+    out = {"depth": t2n(depth), "confidence": t2n(conf), "intrinsics_after": t2n(K)}
+    for s in (1, 2, 3):
+        for it, d in enumerate(dpm[s]):
+            out[f"s{s}_it{it + 1}_depth_out"] = t2n(d)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), tuple(depth.shape), tuple(conf.shape))
+
+
 def dump_ops(path):
     _, _, ref_module = refutil.import_reference()
     g = torch.Generator().manual_seed(7)
@@ -190,6 +217,9 @@ def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "mixed":
         dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
         return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "resized":
+        dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "scene":
         dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
         return
@@ -221,6 +251,7 @@ def main():
     dump_evaluation_io(os.path.join(HERE, "evaluation_io.npz"), model)
     dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
     dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
+    dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
 
 
 if __name__ == "__main__":

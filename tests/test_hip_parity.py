@@ -1000,3 +1000,31 @@ def test_confidence_2x_path_equals_the_general_kernel():
         assert bool((fast[:, ::2, ::2] == fast[:, 1::2, 1::2]).all())
         odd, _ = ops.confidence(score, 2 * h + 3, 2 * w - 1)
         assert odd.shape == (B, 2 * h + 3, 2 * w - 1) and bool(torch.isfinite(odd).all())
+
+
+def test_forward_on_a_size_the_reference_adjusts_against_the_reference():
+    """100 x 130 images (not multiples of 8) against the REFERENCE's own output on the same sample (tests/golden/
+    cascade_resized_100x130.npz, make_golden.py --only resized): adjust_image_dims stretches to 96 x 128 and rescales the caller's
+    intrinsics in place (reference models/net.py:304-318), the final depth comes back bilinearly at 100 x 130 and the confidence by the
+    GENERAL nearest-resize kernel (the cascade's 2x fast path does not apply)."""
+    P = _gpu()
+    g, params, kw = GU.load_npz("cascade_resized_100x130.npz"), GU.load_npz("params_000007.npz"), GU.CASES["default"][2]
+    H, W = 100, 130
+    imgs = [im.to(DEV) for im in synth.synthetic_images(3, H, W)]
+    intr, extr = synth.synthetic_cameras(3, H, W)
+    noise = torch.rand(1, 48, 12, 16, generator=torch.Generator().manual_seed(55)).to(DEV)
+    m = P.PatchmatchNet(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    K = t(intr.copy())
+    with torch.no_grad():
+        depth, conf, dpm = m(imgs, K, t(extr), t(np.array([425.0], np.float32)), t(np.array([935.0], np.float32)), noise=noise)
+    assert tuple(depth.shape) == (1, 1, H, W) and tuple(conf.shape) == (1, H, W)
+    np.testing.assert_array_equal(n(K), g["intrinsics_after"])  # the caller's matrices, mutated exactly as the reference mutates them
+    for st in (3, 2, 1):
+        for it, d in enumerate(dpm[st]):
+            rel = np.abs(n(d) - g[f"s{st}_it{it + 1}_depth_out"]) / g[f"s{st}_it{it + 1}_depth_out"]
+            assert np.quantile(rel, 0.999) < 1e-3 and rel.max() < 2e-2, (st, it, float(rel.max()))
+    rel = np.abs(n(depth) - g["depth"]) / g["depth"]
+    assert float(np.quantile(rel, 0.999)) < 1e-3, float(np.quantile(rel, 0.999))
+    assert float((np.abs(n(conf) - g["confidence"]) > 1e-3).mean()) < 1e-2

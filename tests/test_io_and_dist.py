@@ -362,3 +362,21 @@ def test_f16_split_refuses_weights_outside_float16s_range_and_the_modules_fall_b
     with warnings.catch_warnings(record=True):
         warnings.simplefilter("always")
         assert "conv3_f16s" not in ref._packed() and "conv3" in ref.f16_domain_error
+
+
+def test_adjust_image_dims_mutates_like_the_reference():
+    """adjust_image_dims on CPU tensors against what the REFERENCE left behind on the same 100 x 130 sample (tests/golden/
+    cascade_resized_100x130.npz: reference models/net.py:304-318): the caller's intrinsics, rescaled in place, bit for bit; the
+    caller's image list, now holding the stretched 96 x 128 images; the original size returned for the outputs."""
+    import goldenutil as GU
+    from patchmatchnet_amd.net import adjust_image_dims
+    g = GU.load_npz("cascade_resized_100x130.npz")
+    imgs = synth.synthetic_images(3, 100, 130)
+    intr, _ = synth.synthetic_cameras(3, 100, 130)
+    K = torch.from_numpy(intr.copy())
+    out, K2, h0, w0 = adjust_image_dims(imgs, K)
+    assert K2 is K and (h0, w0) == (100, 130)
+    np.testing.assert_array_equal(K.numpy(), g["intrinsics_after"])
+    assert all(tuple(im.shape) == (1, 3, 96, 128) for im in out) and out is imgs
+    want = torch.nn.functional.interpolate(synth.synthetic_images(3, 100, 130)[1], size=[96, 128], mode="bilinear", align_corners=False)
+    assert torch.equal(out[1], want)
