@@ -23,6 +23,10 @@ Outputs (committed):
                            confidence, every stage / iteration depth, stage-3 view weights and the integer confidence index,
                            FREE-RUNNING from the images (``--only scene``; ~15 s of CPU).  Inputs regenerate from the seeds;
                            ``scene_digest`` pins them.
+  cascade_odd_counts.npz   the released checkpoint under NON-default hypothesis counts, patchmatch_num_sample = [6, 12, 10] (stage 1, 2, 3):
+                           D = 64 / 26 / 20 / 20 / 6 hypotheses per Evaluation call instead of 64 / 32 / 16 / 16 / 8 -- counts that are
+                           no multiple of 4 and none of the compile-time bounds of the HIP kernels; the reference's depth, confidence
+                           and every hot-path intermediate (as cascade_96x128_n2.npz) at 64x96, two source views (``--only counts``).
   cascade_resized_100x130.npz  a 100x130 sample (not multiples of 8): the reference stretches the images to 96x128, rescales the
                            intrinsics in place (models/net.py:304-318), and returns depth (bilinear) and confidence (nearest) at
                            100x130 -- its final depth, confidence, stage depths and the intrinsics it left behind (``--only resized``).
@@ -157,6 +161,19 @@ def dump_mixed(path, model):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+ODD_COUNTS = [6, 12, 10]  # patchmatch_num_sample, stage 1..3 (the parameter shapes do not depend on it: the checkpoint loads as is)
+
+
+def dump_counts(path):
+    ref_net, _, _ = refutil.import_reference()
+    model = ref_net.PatchmatchNet(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+                                  patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=ODD_COUNTS,
+                                  propagate_neighbors=[0, 8, 16], evaluate_neighbors=[9, 9, 9])
+    model.load_state_dict(refutil.load_reference_state_dict(), strict=True)
+    model.eval()
+    dump_cascade(path, model, 3, 64, 96, seed=66)  # the full trace, like the default case (tests/goldenutil.py CASES["counts"])
+
+
 def resized_inputs():
     """Seeded 100x130 sample of the synthetic rig (sizes the reference has to adjust: 100 -> 96, 130 -> 128)."""
     import synth
@@ -217,6 +234,9 @@ def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "mixed":
         dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
         return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "counts":
+        dump_counts(os.path.join(HERE, "cascade_odd_counts.npz"))
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "resized":
         dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
         return
@@ -252,6 +272,7 @@ def main():
     dump_scene(os.path.join(HERE, "cfg2_scene.npz"), model)
     dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
     dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
+    dump_counts(os.path.join(HERE, "cascade_odd_counts.npz"))
 
 
 if __name__ == "__main__":

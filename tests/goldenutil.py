@@ -16,6 +16,12 @@ CASES = {
                 dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
                      patchmatch_iteration=[2, 1, 1], patchmatch_num_sample=[8, 8, 16],
                      propagate_neighbors=[4, 8, 16], evaluate_neighbors=[9, 17, 9])),
+    # the released checkpoint under non-default hypothesis counts: D = 64 / 26 / 20 / 20 / 6 per Evaluation call -- no multiples of 4,
+    # none of the HIP kernels' compile-time bounds (generic hypothesis kernel, run-time-bounded gathers, scalar aggregation)
+    "counts": ("cascade_odd_counts.npz", "params_000007.npz",
+               dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+                    patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[6, 12, 10],
+                    propagate_neighbors=[0, 8, 16], evaluate_neighbors=[9, 9, 9])),
 }
 
 
