@@ -86,8 +86,8 @@ class GraphedForward:
             from . import ops
             static["images"] = [bufs[0]] * len(images)  # shapes for the forward; FeatureNet reads through the table, Refinement entry 0
             static["image_bufs"] = bufs
-            static["image_table"] = ops.SourceTable(torch.zeros(len(images), dtype=torch.int64, device=dev),
-                                                    (len(images),) + tuple(images[0].shape))
+            static["table_all"] = torch.zeros(len(images), dtype=torch.int64, device=dev)
+            static["image_table"] = ops.SourceTable(static["table_all"], (len(images),) + tuple(images[0].shape))
             static["table_host"] = []
         if features is not None and self._table_ok(features):
             # injected pyramids that are channels-last maps of their own (eval.py's encode-once path): only the REFERENCE view's
@@ -100,9 +100,11 @@ class GraphedForward:
             ref = {s: torch.empty((B,) + tuple(features[0][s].shape[2:]) + (features[0][s].shape[1],), dtype=torch.float32, device=dev)
                    for s in stages}
             static["ref_nhwc"] = ref
-            static["tables"] = {s: ops.SourceTable(torch.zeros(len(features) - 1, dtype=torch.int64, device=dev),
-                                                   (len(features) - 1, B) + tuple(features[1][s].shape[2:]) + (features[1][s].shape[1],))
-                                for s in stages}
+            n_src = len(features) - 1
+            static["table_all"] = torch.zeros(len(stages) * n_src, dtype=torch.int64, device=dev)  # [stage-major][view]
+            static["tables"] = {s: ops.SourceTable(static["table_all"][i * n_src:(i + 1) * n_src],
+                                                   (n_src, B) + tuple(features[1][s].shape[2:]) + (features[1][s].shape[1],))
+                                for i, s in enumerate(stages)}
             # (the source entries only carry the count and shapes of the views: stand-ins, so that no sample's pyramids are kept alive)
             static["features"] = [{s: ref[s].permute(0, 3, 1, 2) for s in stages} for _ in range(len(features))]
             static["table_host"] = []  # ring of pinned staging buffers, each guarded by an event
@@ -164,26 +166,23 @@ class GraphedForward:
         torch.rand(size=tuple(static["noise"].shape), out=static["noise"])
 
     @staticmethod
-    def _stage_addresses(static, rows) -> None:
-        """rows: [(device int64 table, [addresses])].  Written through a ring of pinned host buffers, each guarded by an event (the
-        copy is asynchronous: the buffer must not be rewritten before it has been read)."""
+    def _stage_addresses(static, addrs) -> None:
+        """The slot's device tables (``static["table_all"]``: one int64 tensor, the per-stage tables are slices of it) <- ``addrs``,
+        through a ring of pinned host buffers, each guarded by an event (the copy is asynchronous: a buffer must not be rewritten
+        before it has been read).  One numpy assignment and one copy per sample."""
         ring = static["table_host"]
-        total = sum(len(a) for _, a in rows)
         k = static["turn"] = (static.get("turn", -1) + 1) % 8
         if k >= len(ring):
-            ring.append([torch.empty(total, dtype=torch.int64).pin_memory(), None])
-        host, ev = ring[k]
+            host = torch.empty(static["table_all"].numel(), dtype=torch.int64).pin_memory()
+            ring.append([host, host.numpy(), None])
+        host, host_np, ev = ring[k]
         if ev is not None:
             ev.synchronize()  # eight samples back: long done
-        o = 0
-        for table, addrs in rows:
-            for j, a in enumerate(addrs):
-                host[o + j] = a
-            table.copy_(host[o:o + len(addrs)], non_blocking=True)
-            o += len(addrs)
+        host_np[:] = addrs
+        static["table_all"].copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(static["intrinsics"].device))
-        ring[k][1] = ev
+        ring[k][2] = ev
 
     @classmethod
     def _fill(cls, static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
@@ -199,7 +198,7 @@ class GraphedForward:
                     addrs.append(bufs[i].data_ptr())
                 else:
                     addrs.append(im.data_ptr())
-            cls._stage_addresses(static, [(static["image_table"].table, addrs)])
+            cls._stage_addresses(static, addrs)
         else:
             done = set()
             for dst, src in zip(static["images"], images):  # aliased inputs share one static buffer: copied once
@@ -213,10 +212,8 @@ class GraphedForward:
         if features is not None and "tables" in static:
             for s, t in features[0].items():
                 static["features"][0][s].copy_(t, non_blocking=True)
-            stages = sorted(static["tables"])
-            cls._stage_addresses(static, [(static["tables"][s].table,
-                                           [features[1 + v][s].permute(0, 2, 3, 1).data_ptr() for v in range(len(features) - 1)])
-                                          for s in stages])
+            # (the NCHW-shaped view and its channels-last storage start at the same address)
+            cls._stage_addresses(static, [features[1 + v][s].data_ptr() for s in sorted(static["tables"]) for v in range(len(features) - 1)])
         elif features is not None:
             for dst, src in zip(static["features"], features):
                 for s, t in src.items():
