@@ -12,6 +12,7 @@ from patchmatchnet_amd.graph import GraphedForward
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=2.5)
+ap.add_argument("--only", nargs="*", default=None, help="configuration names to run (default: all)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 model = P.PatchmatchNet(**bench.DEFAULT_KW)
@@ -22,6 +23,8 @@ lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "prior
 print("priority range", lo, hi, flush=True)
 CONFIGS = {"3 equal": [0, 0, 0], "3 high/normal/normal": [-1, 0, 0], "3 descending": [-1, 0, 1] if lo >= 1 else [-1, -1, 0],
            "2 equal": [0, 0], "4 equal": [0, 0, 0, 0], "2 high/normal": [-1, 0]}
+if a.only:
+    CONFIGS = {k: v for k, v in CONFIGS.items() if k in a.only}
 main = torch.cuda.current_stream(dev)
 setups = {}
 with torch.no_grad():
@@ -54,6 +57,6 @@ with torch.no_grad():
         for i in range(8):
             replay(name, i)
         torch.cuda.synchronize()
-    run("3 equal", 1.5)
+    run(next(iter(CONFIGS)), 1.5)
     for r in range(2):
         print(f"round {r}: " + "   ".join(f"{name}: {run(name, a.seconds):6.1f}" for name in CONFIGS), flush=True)
