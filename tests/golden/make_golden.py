@@ -27,6 +27,10 @@ Outputs (committed):
                            D = 64 / 26 / 20 / 20 / 6 hypotheses per Evaluation call instead of 64 / 32 / 16 / 16 / 8 -- counts that are
                            no multiple of 4 and none of the compile-time bounds of the HIP kernels; the reference's depth, confidence
                            and every hot-path intermediate (as cascade_96x128_n2.npz) at 64x96, two source views (``--only counts``).
+  cascade_dilations.npz    the released checkpoint under NON-default propagation ranges, propagation_range = [5, 3, 2] (stage 1, 2, 3; default
+                           6 / 4 / 2): other dilations of the offset heads (the fp16-split head kernel instantiates only the defaults:
+                           the fp32 convolution takes over) and other fixed neighbour tables (evaluation dilation = range - 1); full trace
+                           at 64x96, two source views (``--only dilations``).
   cascade_resized_100x130.npz  a 100x130 sample (not multiples of 8): the reference stretches the images to 96x128, rescales the
                            intrinsics in place (models/net.py:304-318), and returns depth (bilinear) and confidence (nearest) at
                            100x130 -- its final depth, confidence, stage depths and the intrinsics it left behind (``--only resized``).
@@ -174,6 +178,19 @@ def dump_counts(path):
     dump_cascade(path, model, 3, 64, 96, seed=66)  # the full trace, like the default case (tests/goldenutil.py CASES["counts"])
 
 
+ODD_RANGES = [5, 3, 2]  # propagation_range, stage 1..3 (no parameter shape depends on it)
+
+
+def dump_dilations(path):
+    ref_net, _, _ = refutil.import_reference()
+    model = ref_net.PatchmatchNet(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=ODD_RANGES,
+                                  patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[8, 8, 16],
+                                  propagate_neighbors=[0, 8, 16], evaluate_neighbors=[9, 9, 9])
+    model.load_state_dict(refutil.load_reference_state_dict(), strict=True)
+    model.eval()
+    dump_cascade(path, model, 3, 64, 96, seed=88)
+
+
 def resized_inputs():
     """Seeded 100x130 sample of the synthetic rig (sizes the reference has to adjust: 100 -> 96, 130 -> 128)."""
     import synth
@@ -237,6 +254,9 @@ def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "counts":
         dump_counts(os.path.join(HERE, "cascade_odd_counts.npz"))
         return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "dilations":
+        dump_dilations(os.path.join(HERE, "cascade_dilations.npz"))
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "resized":
         dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
         return
@@ -273,6 +293,7 @@ def main():
     dump_mixed(os.path.join(HERE, "cascade_mixed_sizes.npz"), model)
     dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
     dump_counts(os.path.join(HERE, "cascade_odd_counts.npz"))
+    dump_dilations(os.path.join(HERE, "cascade_dilations.npz"))
 
 
 if __name__ == "__main__":
