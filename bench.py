@@ -337,6 +337,12 @@ def main():
         local_rank %= torch.cuda.device_count()  # several ranks on one GPU (control-flow test only)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # one process per GPU on a two-socket host: launch thread + pinned buffers on the GPU's own NUMA node (eval.py does the same;
+    # measured there as whole runs alternating between 270 and 380 depth-maps/s without it).  The CPU baseline legs get the
+    # process's original affinity back (they time the host cores, not the launch thread).
+    from patchmatchnet_amd import dist as pdist
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa_note = pdist.bind_to_device_node(device)
     launched = "WORLD_SIZE" in os.environ  # by torch.distributed.run / self_launch: then the process group exists even for one rank
     if launched:                            # (world 1 over RCCL exercises the same init / collectives as world 8: tests/test_bench_gpu.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -511,7 +517,17 @@ def main():
             steady = (n_steady, reduce_scalar(region["run"](n_steady), dist.ReduceOp.MAX))
 
 
-    elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
+    # per-rank spread beside the max-reduced figure, and proof that the collectives saw every rank (a line printed by a job whose
+    # ranks never met would otherwise look like an N-GPU result)
+    elapsed_own = elapsed
+    elapsed_min = reduce_scalar(elapsed_own, dist.ReduceOp.MIN)
+    elapsed = reduce_scalar(elapsed_own, dist.ReduceOp.MAX)
+    ranks_seen = int(round(reduce_scalar(1.0, dist.ReduceOp.SUM)))
+    numa_notes = [numa_note]
+    if launched:
+        numa_notes = [None] * world
+        dist.all_gather_object(numa_notes, numa_note)
+    assert ranks_seen == world, f"the collectives saw {ranks_seen} of {world} ranks"
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -572,6 +588,10 @@ def main():
                        "scene": "photo-consistent rendered surface (tests/synth.render_scene), one texture seed per sample"
                                 if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
+                       "ranks_seen": ranks_seen, "backend": dist.get_backend() if launched else "none (single process, no process group)",
+                       "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 4),
+                       "ms_per_step_rank_max": round(elapsed / args.steps * 1e3, 4),
+                       "numa": numa_notes,
                        "untimed_steps_before_the_timed_region": max(args.warmup, S if not args.eager else 0) + extra_warmup[0],
                        "in_flight": S, "launch": launch_note or ("python, one stream" if args.eager else
                        f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU; images "
@@ -602,6 +622,8 @@ def main():
                                        for k, v in per.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
+            if affinity0 is not None:
+                os.sched_setaffinity(0, affinity0)  # the baselines time the HOST: every core the process was given
             # round 4: the REAL reference timed on this box -- host cores (kind "reference") and, through PyTorch-ROCm, this GPU (the
             # denominator of the north star's 4x); the CPU port of rounds 1-3 stays beside it at one thread count
             ref_cpu = reference_cpu_baseline(H, W, n_src)

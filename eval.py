@@ -44,8 +44,9 @@ def print_args(args) -> None:
 
 def load_model(args, device):
     if args.input_type != "params":
-        raise Exception("--input_type module (TorchScript archive of the reference implementation) cannot carry the HIP "
-                        "path; pass the params checkpoint instead")
+        # the archive's own code is the reference's torch ops; its tensors and constructor lists build the HIP module
+        print("Using scripted module from {}".format(args.checkpoint_path))
+        return P.PatchmatchNet.from_scripted_module(args.checkpoint_path).to(device).eval()
     print("Evaluating model with params from {}".format(args.checkpoint_path))
     model = P.PatchmatchNet(patchmatch_interval_scale=args.patchmatch_interval_scale,
                             propagation_range=args.patchmatch_range, patchmatch_iteration=args.patchmatch_iteration,

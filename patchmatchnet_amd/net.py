@@ -315,6 +315,29 @@ class PatchmatchNet(nn.Module):
             state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    @staticmethod
+    def scripted_module_config(archive) -> Dict[str, list]:
+        """The six constructor lists of a TorchScript archive of the reference's PatchmatchNet (reference eval.py:37-39,
+        checkpoints/module_000007.pt): the scripted module keeps them as readable attributes -- ``patchmatch_num_sample`` on the
+        top module (models/net.py:151), the per-stage scalars on ``patchmatch_1..3`` (models/patchmatch.py:270-286)."""
+        stages = [getattr(archive, f"patchmatch_{i}") for i in (1, 2, 3)]
+        return dict(patchmatch_interval_scale=[float(s.patchmatch_interval_scale) for s in stages],
+                    propagation_range=[int(s.dilation) for s in stages],
+                    patchmatch_iteration=[int(s.patchmatch_iteration) for s in stages],
+                    patchmatch_num_sample=[int(x) for x in archive.patchmatch_num_sample],
+                    propagate_neighbors=[int(s.propagate_neighbors) for s in stages],
+                    evaluate_neighbors=[int(s.evaluate_neighbors) for s in stages])
+
+    @classmethod
+    def from_scripted_module(cls, path: str) -> "PatchmatchNet":
+        """``--input_type module`` (reference eval.py:37-39): the archive carries the reference's own code, which cannot run the HIP
+        path -- but also everything needed to build the HIP module: the 242 state-dict tensors under the same names and the
+        constructor lists (the command line's patchmatch flags are ignored, as the reference ignores them for a module)."""
+        archive = torch.jit.load(path, map_location="cpu")
+        model = cls(**cls.scripted_module_config(archive))
+        model.load_state_dict({k: v.detach().clone() for k, v in archive.state_dict().items()}, strict=True)
+        return model
+
     def extract_features(self, images: List[torch.Tensor], stacked: Optional[dict] = None,
                          image_table: Optional["ops.SourceTable"] = None) -> List[Dict[int, torch.Tensor]]:
         """Per-view feature pyramids.  ``stacked`` (a dict) additionally receives {stage: [V*B,C,h,w]} when all views

@@ -33,6 +33,10 @@ def _check(line: dict, n_gpus: int) -> None:
     assert r["launches"] == 5 * r["steps_with_events"]  # five pmn_warp_correlate launches per depth map
     assert r["tap_bytes_per_step"] > r["alg_bytes_per_step"] and 0 < r["l1_frac"] < 1
     assert line["steady_state"]["steps"] >= line["steps"] and line["steady_state"]["value"] > 0
+    c = line["config"]
+    # the collectives saw every rank, the spread over ranks brackets the max-reduced figure, every rank reports its NUMA binding
+    assert c["ranks_seen"] == n_gpus and len(c["numa"]) == n_gpus and all(isinstance(x, str) and x for x in c["numa"])
+    assert c["ms_per_step_rank_min"] <= c["ms_per_step_rank_max"] and abs(c["ms_per_step_rank_max"] - line["ms_per_step"]) < 1e-3
 
 
 def test_bench_line_default_and_eager():
@@ -61,6 +65,7 @@ def test_bench_two_ranks_on_one_gpu():
     _check(line, 2)
     assert "{" not in outs[1][0]  # only rank 0 prints
     assert line["config"]["in_flight"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["backend"] == "gloo"
 
 
 def test_bench_one_rank_over_rccl():
@@ -74,7 +79,9 @@ def test_bench_one_rank_over_rccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600,
                        cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    _check(_line(p.stdout), 1)
+    line = _line(p.stdout)
+    _check(line, 1)
+    assert line["config"]["backend"] == "nccl"
 
 
 def test_bench_self_launches_its_ranks():

@@ -56,3 +56,30 @@ def test_archive_agrees_with_the_oracle():
     want = dpm[1][-1].numpy()  # stage-1 depth before refinement
     rel = np.abs(d1 - want) / np.abs(want)
     assert float(np.median(rel)) < 1e-5 and float((rel > 1e-3).mean()) < 2e-2, (float(np.median(rel)), float((rel > 1e-3).mean()))
+
+
+def test_input_type_module_builds_the_hip_module_from_the_archive():
+    """`eval.py --input_type module` (reference eval.py:37-39): the TorchScript archive's 242 tensors and its six constructor lists
+    build patchmatchnet_amd.PatchmatchNet -- same names, same values as the params checkpoint gives; a variant archive (other
+    sample / neighbour counts) round-trips its own lists."""
+    path, make_ref = _archive()
+    import eval as ev
+    import patchmatchnet_amd as P
+    args = ev.build_parser().parse_args(["--input_folder", "x", "--output_folder", "y", "--checkpoint_path", path,
+                                         "--input_type", "module"])
+    model = ev.load_model(args, torch.device("cpu"))
+    assert isinstance(model, P.PatchmatchNet) and not model.training
+    kw = P.PatchmatchNet.scripted_module_config(torch.jit.load(path, map_location="cpu"))
+    assert kw == make_ref.DEFAULT_KW, kw
+    with np.load(os.path.join(ROOT, "tests", "golden", "params_000007.npz")) as z:
+        want = {k: z[k] for k in z.files}
+    got = model.state_dict()
+    assert set(got) == set(want) and len(got) == 242
+    for k, v in want.items():
+        np.testing.assert_array_equal(got[k].numpy(), v, err_msg=k)
+    # the reference's shipped archive, where the checkout exists (it is the file the reference's README passes to --input_type module)
+    shipped = "/root/reference/checkpoints/module_000007.pt"
+    if os.path.isfile(shipped):
+        m2 = P.PatchmatchNet.from_scripted_module(shipped)
+        for k, v in want.items():
+            np.testing.assert_array_equal(m2.state_dict()[k].numpy(), v, err_msg=k)
