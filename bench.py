@@ -190,10 +190,16 @@ def reference_rocm_baseline(H, W, n_src, device, ours, warmup=3, timed=10, budge
                     break
             torch.manual_seed(1234)
             mine, _, _ = ours([im for im in args[0]], args[1].clone(), args[2], args[3], args[4])
+            # ... and with the reference's OWN FeatureNet outputs on this GPU (MIOpen) handed to this engine's cascade: what is left is
+            # the cascade's share of the difference (tests/test_fullsize_parity.py::test_cfg2_scene_against_the_reference_on_rocm gates it)
+            ref_feats = [{s_: f_.contiguous() for s_, f_ in model.feature(im).items()} for im in args[0]]
+            torch.manual_seed(1234)
+            forced, _, _ = ours([im for im in args[0]], args[1].clone(), args[2], args[3], args[4], features=ref_feats)
             torch.cuda.synchronize()
         tt = times[warmup:]
         med = float(np.median(tt))
         rel = ((mine - ref_depth).abs() / ref_depth.abs()).flatten().double()
+        relf = ((forced - ref_depth).abs() / ref_depth.abs()).flatten().double()
         out.update({"value": round(1.0 / med, 3), "unit": "depth-maps/s", "ms_per_forward": round(med * 1e3, 2), "samples": len(tt),
                     "warmup_seconds": [round(t, 2) for t in times[:warmup]],
                     "min_ms": round(min(tt) * 1e3, 2), "max_ms": round(max(tt) * 1e3, 2),
@@ -201,7 +207,13 @@ def reference_rocm_baseline(H, W, n_src, device, ours, warmup=3, timed=10, budge
                         "what": "final depth of this engine vs the reference's on the same sample and the same seeded stage-3 draw, "
                                 "both free-running on this GPU (relative difference)",
                         "p50": float(rel.median()), "p99": float(torch.quantile(rel[:: max(1, rel.numel() // 1000000)], 0.99)),
-                        "frac_gt_1e-3": float((rel > 1e-3).double().mean()), "max": float(rel.max())}})
+                        "frac_gt_1e-3": float((rel > 1e-3).double().mean()), "max": float(rel.max())},
+                    "parity_vs_this_engine_on_the_reference_features": {
+                        "what": "the same comparison with the reference's own FeatureNet outputs on this GPU (MIOpen) handed to this engine "
+                                "(features=): the cascade + refinement's share of the difference; the rest of `parity_vs_this_engine` is "
+                                "MIOpen's FeatureNet vs this engine's (profiles/r05_rocm_parity.md)",
+                        "p50": float(relf.median()), "p99": float(torch.quantile(relf[:: max(1, relf.numel() // 1000000)], 0.99)),
+                        "frac_gt_1e-3": float((relf > 1e-3).double().mean()), "max": float(relf.max())}})
         del model
         torch.cuda.empty_cache()
     except Exception as e:  # the baseline must never take the bench line down

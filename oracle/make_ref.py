@@ -26,6 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_DIR = os.path.join(ROOT, "oracle", "_ref")
 ARCHIVE = os.path.join(OUT_DIR, "patchmatchnet_reference.pt")
+PINNED = os.path.join(OUT_DIR, "patchmatchnet_reference_pinned.pt")  # same network, stage-3 draw read from a buffer (see pinned_draw)
 META = os.path.join(OUT_DIR, "patchmatchnet_reference.json")
 
 DEFAULT_KW = dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
@@ -48,11 +49,39 @@ def known_answer_inputs(n_views=3, H=64, W=80):
     return imgs, torch.from_numpy(intr), torch.from_numpy(extr), torch.tensor([425.0]), torch.tensor([935.0])
 
 
+def pinned_draw(inner):
+    """Wraps the reference's DepthInitialization module so that the stage-3 random draw can be HANDED IN: the one line of the
+    reference that keeps two runs on different devices from being comparable is ``torch.rand(..., device=device)``
+    (models/patchmatch.py:61-62) -- the CPU and the ROCm generator produce different streams under the same seed.  The wrapper reads
+    the uniform draw from its ``noise`` attribute ([B,48,h,w], assigned by the caller on the loaded archive) and maps it to the 48
+    inverse-depth bins as models/patchmatch.py:63-71 does; every other call goes to the unmodified reference module.  Pinned to the
+    unmodified archive bit for bit in tests/test_reference_archive.py (same CPU draw handed in == the seed's own draw)."""
+    import torch
+
+    class PinnedDraw(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+            self.register_buffer("noise", torch.zeros(1, 48, 1, 1), persistent=False)
+
+        def forward(self, min_depth: torch.Tensor, max_depth: torch.Tensor, height: int, width: int,
+                    depth_interval_scale: float, device: torch.device, depth: torch.Tensor) -> torch.Tensor:
+            if depth.numel() == 0:
+                nb = min_depth.size()[0]
+                bins = self.noise + torch.arange(start=0, end=48, step=1, device=device).view(1, 48, 1, 1)
+                far = (1.0 / max_depth).view(nb, 1, 1, 1)
+                near = (1.0 / min_depth).view(nb, 1, 1, 1)
+                return 1.0 / (far + bins / 48 * (near - far))
+            return self.inner(min_depth, max_depth, height, width, depth_interval_scale, device, depth)
+
+    return PinnedDraw(inner)
+
+
 def build(reference="/root/reference", force=False, verbose=True):
     """Returns the archive path, or None when the reference checkout is not there (the GPU box: the prebuilt file is used)."""
     if not os.path.isdir(os.path.join(reference, "models")):
         return ARCHIVE if os.path.isfile(ARCHIVE) else None
-    if os.path.isfile(ARCHIVE) and os.path.isfile(META) and not force:
+    if os.path.isfile(ARCHIVE) and os.path.isfile(META) and os.path.isfile(PINNED) and not force:
         return ARCHIVE
     import torch
     sys.path.insert(0, reference)
@@ -69,6 +98,9 @@ def build(reference="/root/reference", force=False, verbose=True):
     scripted = torch.jit.script(model)
     os.makedirs(OUT_DIR, exist_ok=True)
     scripted.save(ARCHIVE)
+    # the same network with the stage-3 draw handed in (CPU <-> ROCm comparisons of the reference with itself need one draw)
+    model.patchmatch_3.depth_initialization = pinned_draw(model.patchmatch_3.depth_initialization)
+    torch.jit.script(model).save(PINNED)
     # known answer on the CPU backend (seeded stage-3 draw), for the loader on the other side
     imgs, intr, extr, dmin, dmax = known_answer_inputs()
     torch.manual_seed(1234)

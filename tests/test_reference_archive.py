@@ -83,3 +83,34 @@ def test_input_type_module_builds_the_hip_module_from_the_archive():
         m2 = P.PatchmatchNet.from_scripted_module(shipped)
         for k, v in want.items():
             np.testing.assert_array_equal(m2.state_dict()[k].numpy(), v, err_msg=k)
+
+
+def test_pinned_draw_archive_is_the_reference_bit_for_bit():
+    """oracle/_ref/patchmatchnet_reference_pinned.pt = the same scripted reference with the stage-3 draw handed in (make_ref.pinned_draw;
+    reference models/patchmatch.py:56-71).  Handing it the CPU generator's own draw under a seed must reproduce the unmodified archive
+    under that seed BIT FOR BIT -- depth, confidence and every stage's depth maps: it is then the reference, with one tensor pinned."""
+    path, make_ref = _archive()
+    if not os.path.isfile(make_ref.PINNED):
+        pytest.skip("prebuilt oracle/_ref has no pinned-draw archive")
+    ref = torch.jit.load(path, map_location="cpu").eval()
+    pin = torch.jit.load(make_ref.PINNED, map_location="cpu").eval()
+    imgs, intr, extr, dmin, dmax = make_ref.known_answer_inputs()
+    H, W = imgs[0].shape[2:]
+    torch.manual_seed(99)
+    noise = torch.rand(1, 48, H // 8, W // 8)
+    pin.patchmatch_3.depth_initialization.noise = noise
+    with torch.no_grad():
+        torch.manual_seed(99)
+        d0, c0, p0 = ref(imgs, intr.clone(), extr, dmin, dmax)
+        torch.manual_seed(12345)  # (ignored by the pinned archive)
+        d1, c1, p1 = pin(imgs, intr.clone(), extr, dmin, dmax)
+    assert torch.equal(d0, d1) and torch.equal(c0, c1)
+    for st in (3, 2, 1):
+        assert len(p0[st]) == len(p1[st])
+        for a, b in zip(p0[st], p1[st]):
+            assert torch.equal(a, b)
+    # and a different draw moves the result (the buffer is really what the network reads)
+    pin.patchmatch_3.depth_initialization.noise = 1.0 - noise
+    with torch.no_grad():
+        d2, _, _ = pin(imgs, intr.clone(), extr, dmin, dmax)
+    assert not torch.equal(d0, d2)
