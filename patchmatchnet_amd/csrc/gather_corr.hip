@@ -94,13 +94,25 @@ __device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, co
 // form, east corner through the immediate offset field (no 64-bit VALU address arithmetic).
 struct PmnCorners { float4 t00, t01, t10, t11; };
 
+// (The view's base may come out of a device table of addresses -- an integer turned pointer, whose address space hipcc cannot know:
+// it then emits flat_load_dwordx4 on a 64-bit VGPR address built with a v_lshl_add_u64 per corner pair, and a FLAT access also
+// occupies the LDS queue and both wait counters.  The maps are global memory: the explicit address space gives
+// global_load_dwordx4 v, v_offset, s[base] offset:imm.)
+typedef float pmn_f4n __attribute__((ext_vector_type(4)));  // (a native vector: HIP's float4 class cannot be read through an address-space pointer)
+typedef const pmn_f4n __attribute__((address_space(1))) * pmn_gptr4;
+__device__ __forceinline__ float4 pmn_global_load4(const char __attribute__((address_space(1))) * p) {
+    const pmn_f4n v = *(pmn_gptr4)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 template <int C>
 __device__ __forceinline__ PmnCorners load_corners(const char* __restrict__ sbase, const unsigned bo, const unsigned row_bytes) {
+    typedef const char __attribute__((address_space(1))) * gptr1;
+    const gptr1 g = (gptr1)sbase;
     PmnCorners c;
-    c.t00 = *reinterpret_cast<const float4*>(sbase + bo);
-    c.t01 = *reinterpret_cast<const float4*>(sbase + bo + C * 4);
-    c.t10 = *reinterpret_cast<const float4*>(sbase + (bo + row_bytes));
-    c.t11 = *reinterpret_cast<const float4*>(sbase + (bo + row_bytes) + C * 4);
+    c.t00 = pmn_global_load4(g + bo);
+    c.t01 = pmn_global_load4(g + bo + C * 4);
+    c.t10 = pmn_global_load4(g + (bo + row_bytes));
+    c.t11 = pmn_global_load4(g + (bo + row_bytes) + C * 4);
     return c;
 }
 
@@ -574,6 +586,280 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
     }
 }
 
+// ---- PixelwiseNet launch, wave-private form (round 5) -----------------------------------------------------------------
+// MODE_PIXELWISE of the kernel above hands every view's similarity tile from the lane role to the item role ACROSS the workgroup:
+// three workgroup barriers, 64 ds_write_b32 + 32 ds_read_b32 + one 64-bit LDS atomic max per wave and view (round 4's counters:
+// LDS 32 % busy, 20 % of the wave cycles waiting, 3 waves per SIMD).  Here a WAVE owns its pixels from the gather to the view
+// weight: the lane groups that gather pixel p and the lanes that run PixelwiseNet on pixel p's hypotheses sit in the same wave, so
+//   * the hand-over is wave-private LDS (a wave's LDS instructions execute in order: no barrier anywhere in the view loop, every
+//     wave streams on its own as in MODE_VIEWS);
+//   * an owner lane parks four consecutive hypotheses with ONE ds_write_b128 (row = (pixel, group), hypothesis fastest) and an
+//     item-role lane -- (pixel, NIT consecutive hypotheses) -- fetches a group's NIT values with one ds_read_b128 / b64;
+//   * the max over D is a DPP max over the 16 (PW = 4) or 32 (PW = 2) lanes of the pixel on the 64-bit (response bits | ~d) key
+//     -- no atomic, no key array --, and the view's similarities stay in the item lane's registers for the weighted sum.
+// PW = pixels per wave: 4 = one 16-lane group per pixel walks all 64 hypotheses; 2 = two groups per pixel walk 32 each, half the
+// work per wave in twice as many waves (the launch is 7500 waves of PW = 4 over 3072-4096 wave slots: a short tail).
+// Every (pixel, hypothesis, view) goes through exactly the operations of the kernel above in the same order; the max is order-free:
+// same bits (scripts/ab_forward_bits.py).  C = 64, G = 8, D <= 64 (the cascade's stage 3); other shapes use the kernel above.
+template <int LPI>
+__device__ __forceinline__ void bcast_record(const int sl, const float r00, const float r01, const float r10, const float r11,
+                                             const int ro, float4& w4, int& off) {
+#define PMN_BCAST_CASE(SL)                      \
+    case SL:                                    \
+        w4.x = group_bcast_f<LPI, SL>(r00);     \
+        w4.y = group_bcast_f<LPI, SL>(r01);     \
+        w4.z = group_bcast_f<LPI, SL>(r10);     \
+        w4.w = group_bcast_f<LPI, SL>(r11);     \
+        off = group_bcast_i<LPI, SL>(ro);       \
+        break;
+    switch (sl) {
+        PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
+        PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
+        PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
+        PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
+        default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
+    }
+#undef PMN_BCAST_CASE
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(const unsigned long long v) {
+    const int lo = (int)(unsigned)(v & 0xFFFFFFFFull), hi = (int)(unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+
+#ifndef PMN_PW
+#define PMN_PW 2  // pixels per wave of the PixelwiseNet launch (4 or 2; 0 = the workgroup-tile kernel above)
+#endif
+#ifndef PMN_PW_WAVES
+#define PMN_PW_WAVES 4  // waves per SIMD the launch is compiled for
+#endif
+
+template <int PW, bool EXACT>
+__global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel(const GatherArgs a) {
+    constexpr int C = 64, G = 8, DT = 64, LPI = 16, CG = 8, LPG = 2;
+    constexpr int LGP = 4 / PW;            // lane groups per pixel
+    constexpr int DL = DT / LGP;           // hypotheses a lane group walks: its block [k*DL, (k+1)*DL)
+    constexpr int RPL = DL / LPI;          // hypotheses a lane projects per view
+    constexpr int LPP = 64 / PW;           // item role: lanes per pixel
+    constexpr int NIT = DT / LPP;          // item role: consecutive hypotheses per lane (4 or 2)
+    constexpr int GS = DT + 4;             // LDS row pitch (floats): rows of the 8 groups start 17 x 16 B apart
+    constexpr int PS = G * GS;             // LDS floats per pixel
+    constexpr int WPB = PMN_BLOCK / 64;    // waves per workgroup
+    constexpr int NPIX = WPB * PW;         // pixels per workgroup
+    static_assert(PW == 4 || PW == 2, "pixels per wave");
+    static_assert(NIT % 2 == 0, "PixelwiseNet runs on pairs of items");
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int tile = pmn_xcd_tile(blockIdx.x, a.ntiles);
+    const int D = EXACT ? DT : a.D;
+    const int N = a.N, h = a.h, w = a.w, hs = a.hs, ws = a.ws;
+    const int hw = h * w;
+    const int pw0 = tile * NPIX + wave * PW;  // first pixel of this wave
+
+    extern __shared__ float4 smem4[];
+    float* wlds_a = reinterpret_cast<float*>(smem4);   // SimilarityNet weights
+    float* wlds_b = wlds_a + MLP_LDS_FLOATS;           // PixelwiseNet weights
+    float* simw = wlds_b + MLP_LDS_FLOATS + wave * (PW * PS);  // this wave's [PW][G][GS] similarity rows
+    for (int i = tid; i < PMN_MLP_FLOATS; i += PMN_BLOCK) {
+        wlds_a[i] = a.mlp_a[i];
+        wlds_b[i] = a.mlp_b[i];
+    }
+    __syncthreads();  // the only workgroup barrier
+
+    // lane role: lane lc of lane group lg gathers block k of pixel pl
+    const int lg = lane >> 4, lc = lane & 15;
+    const int pl = lg / LGP, k = lg % LGP;
+    const int pB = pw0 + pl;
+    const bool okB = pB < hw;
+    float4 refq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (okB) refq = reinterpret_cast<const float4*>(a.ref)[((size_t)b * hw + pB) * LPI + lc];
+    const int yB = okB ? pB / w : 0, xB = okB ? pB - yB * w : 0;
+    const bool owner = (lc % LPG) == 0;
+    const int gB = lc / LPG;
+    float rdep[RPL];
+    bool rok[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        const int d = k * DL + lc + j * LPI;
+        rok[j] = okB && (EXACT || d < D);
+        rdep[j] = rok[j] ? a.depth[((size_t)b * D + d) * hw + pB] : 1.0f;
+    }
+    float* srow = simw + pl * PS + gB * GS + k * DL;  // owner lanes: this (pixel, group) row, my block
+
+    // item role: lane q of the LPP lanes of pixel pi runs the pointwise nets on hypotheses [d0, d0 + NIT)
+    const int pi = lane / LPP, q = lane % LPP;
+    const int d0 = q * NIT;
+    const int pA = pw0 + pi;
+    const bool okA = pA < hw;
+    const float* xrow = simw + pi * PS + d0;
+
+    float ssum[NIT][G];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ssum[j][g] = 0.0f;
+    float wsum = 1e-5f;
+    const float xf = (float)xB, yf = (float)yB;
+    const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
+
+    for (int v = 0; v < N; ++v) {
+        // ---- lane role: project my RPL hypotheses (records stay in registers), then walk the block ----------------------------
+        const PmnPose lane_pose = pmn_make_pose(a.proj + ((size_t)b * N + v) * 16, xf, yf, h, w);
+        float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
+        int roff[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            PmnTaps t;
+            t.off = 0;
+            t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+            if (rok[j]) {
+                float ix, iy;
+                pmn_pose_position(lane_pose, rdep[j], h, w, hs, ws, ix, iy);
+                t = pmn_make_taps(ix, iy, hs, ws);
+            }
+            rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
+            roff[j] = t.off;
+        }
+        const char* sbase = pmn_view_base<C>(a, v, b, hs, ws);
+        constexpr int NB = 2;
+#pragma unroll
+        for (int i0 = 0; i0 < DL; i0 += 2 * NB) {
+            float sv[2 * NB];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                PmnCorners cn[NB];
+                float4 wq[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int il = i0 + hb * NB + i;  // position in the block; hypothesis d = k*DL + il
+                    float4 w4;
+                    int off;
+                    bcast_record<LPI>(il % LPI, rw00[il / LPI], rw01[il / LPI], rw10[il / LPI], rw11[il / LPI], roff[il / LPI], w4, off);
+                    wq[i] = w4;
+                    cn[i] = load_corners<C>(sbase, (unsigned)off * (C * 4) + lane_bytes, row_bytes);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) sv[hb * NB + i] = blend_corners<LPG, CG>(cn[i], wq[i], refq);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (owner) *reinterpret_cast<float4*>(srow + i0) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- item role: PixelwiseNet on my NIT hypotheses of this view, max over the pixel's lanes --------------------------
+        // (NIT = 4: the rows are fetched pair by pair for the net and again for the weighted sum -- 16 more LDS reads per view instead
+        //  of 32 registers live across the net, which is what decides between 4 waves per SIMD with and without scratch)
+        float x[NIT][G];
+        if constexpr (NIT == 2) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float2 t2 = *reinterpret_cast<const float2*>(xrow + g * GS);
+                x[0][g] = t2.x; x[1][g] = t2.y;
+            }
+        }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int c = 0; c < NIT / 2; ++c) {
+            pmn_f2 xq[1][G], rq[1];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if constexpr (NIT == 2) {
+                    xq[0][g] = pmn_f2{x[0][g], x[1][g]};
+                } else {
+                    const float2 t2 = *reinterpret_cast<const float2*>(xrow + g * GS + 2 * c);
+                    xq[0][g] = pmn_f2{t2.x, t2.y};
+                }
+            }
+            mlp_pairs_from_lds<G, 1>(wlds_b, xq, rq);
+            const float r[2] = {rq[0].x, rq[0].y};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int d = d0 + 2 * c + i;
+                if (EXACT || d < D) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(pmn_sigmoid(r[i])) << 32) |
+                                                   (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
+                    best = key > best ? key : best;
+                }
+            }
+        }
+        best = dpp_max_u64<0xB1>(best);   // quad_perm [1,0,3,2]
+        best = dpp_max_u64<0x4E>(best);   // quad_perm [2,3,0,1]
+        best = dpp_max_u64<0x124>(best);  // row_ror:4
+        best = dpp_max_u64<0x128>(best);  // row_ror:8  -> every lane of a 16-lane row holds the row's max
+        if constexpr (LPP == 32) {
+            const unsigned long long o = __shfl_xor(best, 16, 64);
+            best = o > best ? o : best;
+        }
+        const float vwp = __uint_as_float((unsigned)(best >> 32));
+        if constexpr (NIT == 4) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 t4 = *reinterpret_cast<const float4*>(xrow + g * GS);
+                x[0][g] = t4.x; x[1][g] = t4.y; x[2][g] = t4.z; x[3][g] = t4.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+#pragma unroll
+            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], x[j][g], vwp);
+        wsum += vwp;
+        if (q == 0 && okA) {
+            const size_t o = ((size_t)b * N + v) * hw + pA;
+            a.vw_out[o] = vwp;
+            if (a.vw_argmax) a.vw_argmax[o] = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the next view's rows are written after these reads: same wave, LDS executes in order)
+    }
+
+    if (!okA) return;
+    float o[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ssum[j][g] = ssum[j][g] / wsum;
+    mlp_items<G, NIT, 2>(wlds_a, ssum, o);
+    float* orow = a.out + ((size_t)b * hw + pA) * D + d0;  // cost is hypothesis-last [B,h,w,D]
+    if constexpr (EXACT) {
+        if constexpr (NIT == 4) *reinterpret_cast<float4*>(orow) = make_float4(o[0], o[1], o[2], o[3]);
+        else *reinterpret_cast<float2*>(orow) = make_float2(o[0], o[1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+            if (d0 + j < D) orow[j] = o[j];
+    }
+    if (a.sim_out) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+            if (d0 + j < D) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d0 + j) * hw + pA] = ssum[j][g];
+            }
+    }
+}
+
+template <int PW>
+static int launch_pixelwise_wave(GatherArgs& a, hipStream_t stream) {
+    constexpr int NPIX = (PMN_BLOCK / 64) * PW, PS = 8 * (64 + 4);
+    a.ntiles = (a.h * a.w + NPIX - 1) / NPIX;
+    const size_t lds = (size_t)2 * MLP_LDS_FLOATS * 4 + (size_t)NPIX * PS * 4;
+    if (a.D == 64) {
+        hipLaunchKernelGGL((pixelwise_wave_kernel<PW, true>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((pixelwise_wave_kernel<PW, false>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
+    }
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 
 template <int C, int G, int MODE, int DT, bool EXACT>
@@ -680,6 +966,9 @@ static int warp_correlate_impl(const float* ref_nhwc, const float* src_nhwc, con
     }
 #endif
     if (view_weights_in) return dispatch_gather<MODE_VIEWS>(a, C, G, (hipStream_t)stream);
+#if PMN_PW != 0
+    if (C == 64 && G == 8 && D <= 64) return launch_pixelwise_wave<PMN_PW>(a, (hipStream_t)stream);  // the cascade's stage 3
+#endif
     return dispatch_gather<MODE_PIXELWISE>(a, C, G, (hipStream_t)stream);
 }
 

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 5 A/B builds of libpmn_hip.so for the PixelwiseNet launch (scripts/gpu_r5_pixelwise_ab.sh runs them on one box):
+#   base   gather_corr.hip of the given git revision (default: round 4's last commit c9b86bd): flat corner loads, workgroup-tile PixelwiseNet
+#   g0     this tree, -DPMN_PW=0: global corner loads, workgroup-tile PixelwiseNet kernel
+#   g4     this tree, wave-private PixelwiseNet, 4 pixels per wave     g2 / g2w5: 2 pixels per wave at 4 / 5 waves per SIMD
+# Only gather_corr.hip differs; the other objects are the tree's.  Output: build/pw/libpmn_hip_<variant>.so (git-ignored, travels with gpurun).
+set -e
+cd "$(dirname "$0")/.."
+REV=${1:-c9b86bd}
+CS=patchmatchnet_amd/csrc
+make -s -C $CS -j8
+mkdir -p build/pw
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -I$CS"
+OTHERS=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v gather_corr.o)
+git show $REV:$CS/gather_corr.hip > build/pw/gather_corr_base.hip
+sed -i 's#"gather_common.hpp"#"../../patchmatchnet_amd/csrc/gather_common.hpp"#' build/pw/gather_corr_base.hip
+build() { # name source defines...
+  local name=$1 src=$2; shift 2
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o build/pw/gather_corr_$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_$name.so build/pw/gather_corr_$name.o $OTHERS
+  echo "built build/pw/libpmn_hip_$name.so"
+}
+build base build/pw/gather_corr_base.hip &
+build g0 $CS/gather_corr.hip -DPMN_PW=0 &
+build g4 $CS/gather_corr.hip -DPMN_PW=4 -DPMN_PW_WAVES=4 &
+build g2 $CS/gather_corr.hip -DPMN_PW=2 -DPMN_PW_WAVES=4 &
+build g2w5 $CS/gather_corr.hip -DPMN_PW=2 -DPMN_PW_WAVES=5 &
+wait
