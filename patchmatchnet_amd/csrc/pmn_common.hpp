@@ -137,9 +137,15 @@ __device__ __forceinline__ float pmn_div(float n, float d) { return pmn_div_by(n
 __device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y, int h, int w) {
 #pragma clang fp contract(off)
     PmnPose q;
+#ifdef PMN_POSE_FMA  // attribution build (scripts/rocm_parity_probe.py): rot @ [x y 1]^T as a GEMM's k-ordered fma chain (what a BLAS on the GPU does)
+    q.rx = fmaf(P[2], 1.0f, fmaf(P[1], y, P[0] * x));
+    q.ry = fmaf(P[6], 1.0f, fmaf(P[5], y, P[4] * x));
+    q.rz = fmaf(P[10], 1.0f, fmaf(P[9], y, P[8] * x));
+#else
     q.rx = (P[0] * x + P[1] * y) + P[2];
     q.ry = (P[4] * x + P[5] * y) + P[6];
     q.rz = (P[8] * x + P[9] * y) + P[10];
+#endif
     q.tx = P[3];
     q.ty = P[7];
     q.tz = P[11];

@@ -26,3 +26,7 @@ build g4 $CS/gather_corr.hip -DPMN_PW=4 -DPMN_PW_WAVES=4 &
 build g2 $CS/gather_corr.hip -DPMN_PW=2 -DPMN_PW_WAVES=4 &
 build g2w5 $CS/gather_corr.hip -DPMN_PW=2 -DPMN_PW_WAVES=5 &
 wait
+# attribution build for scripts/rocm_parity_probe.py: rot @ [x y 1]^T as a k-ordered fma chain (-DPMN_POSE_FMA), everything else the tree's
+( /opt/rocm/bin/hipcc $FLAGS -DPMN_POSE_FMA -c $CS/gather_corr.hip -o build/pw/gather_corr_posefma.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_posefma.so build/pw/gather_corr_posefma.o $OTHERS
+  echo "built build/pw/libpmn_hip_posefma.so" )
