@@ -196,8 +196,8 @@ class ViewDecodeStream:
         self.busy = still
 
     def take(self, max_n: int = 4):
-        """[(group, view id, image [1,3,H,W] float32 on the device)], 1..max_n consecutive views of ONE group; the current stream is
-        ordered after their uploads."""
+        """[(group, view id, image [1,3,H,W] float32 on the device, the decoded [H,W,3] uint8 / float32 it was made from)], 1..max_n
+        consecutive views of ONE group; the current stream is ordered after their uploads."""
         self._fill()
         self._recycle()
         if not self.pending:
@@ -217,7 +217,7 @@ class ViewDecodeStream:
             self.busy.append((ev, buf))
             torch.cuda.current_stream(self.device).wait_event(ev)
             img.record_stream(torch.cuda.current_stream(self.device))
-            out.append((item[0], item[3], img))
+            out.append((item[0], item[3], img, raw))  # raw: the decoded [H,W,3] as uploaded (the fusion stage's point colours)
             self._fill()
         return out
 
@@ -337,7 +337,7 @@ def _encode_once_ok(dataset, scan, light, views):
     return h % 8 == 0 and w % 8 == 0
 
 
-def save_depth(args, rank, world, device, on_scan_done=None):
+def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
     """Runs the network over this rank's reference views and writes depth / confidence maps (reference eval.py:20-82).
 
     ``on_scan_done(scan, produced)`` is called as soon as every (scan, light) group of a scan has been inferred (--output_type both:
@@ -397,6 +397,9 @@ def save_depth(args, rank, world, device, on_scan_done=None):
             on_scan_done(scan, produced)
             for key in [k for k in produced if k[0] == scan]:
                 del produced[key]
+            if scan_images is not None:
+                for key in [k for k in scan_images if k[0] == scan]:
+                    del scan_images[key]  # (the fusion job holds its own references until the scan's points are on the host)
 
     # ---- streaming encode-once plan: which groups qualify, their views in first-use order, one loader for all of them ----------
     group_list = [(scan, light, indices) for scan in dataset.scans for light, indices in by_scan.get(scan, [])]
@@ -445,11 +448,16 @@ def save_depth(args, rank, world, device, on_scan_done=None):
             while any(v not in pyramids for v in ids):  # decode stream order = first-use order: the next views are these
                 batch = view_stream.take(4)
                 assert batch[0][0] == gi, "view stream out of step with the sample order"
-                f = model.feature.forward_hip([img for _, _, img in batch])  # 1..4 views in one FeatureNet pass
-                for j, (_, v, img) in enumerate(batch):
+                f = model.feature.forward_hip([img for _, _, img, _ in batch])  # 1..4 views in one FeatureNet pass
+                for j, (_, v, img, raw) in enumerate(batch):
                     pyramids[v] = {s: t[j:j + 1].permute(0, 3, 1, 2) for s, t in f.items()}  # NCHW-shaped views, NHWC storage
                     if v in refs:
                         images[v] = img  # Refinement reads the reference image
+                        # ... and the fusion stage takes the point colours from the same decoded bytes, when this IS the file it
+                        # would read (reference eval.py:212: <scan>/images/<view>.jpg, whatever the light folder of the sample)
+                        if scan_images is not None and os.path.normpath(dataset.image_path(scan, light, v)) == os.path.normpath(
+                                os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(v))):
+                            scan_images[(scan, v)] = raw
                     n_enc += 1
             ref_img = images[ids[0]]
             _seed_sample(args, dataset, sample)
@@ -549,6 +557,7 @@ def save_depth(args, rank, world, device, on_scan_done=None):
     print("depth stage: {} samples in {:.3f} s after a {:.3f} s model load -> {:.1f} depth-maps/s on this rank (decode, upload, "
           "forward, download and map files included)".format(total, t_end - t_loaded, t_loaded - t_stage,
                                                              total / max(t_end - t_loaded, 1e-9)))
+    args._depth_stage = (total, t_loaded)  # main(): --output_type both reports its end-to-end rate from the same starting point
     return produced
 
 
@@ -564,11 +573,61 @@ def _scan_cameras(args, scan, view_ids):
     return cams, sizes
 
 
-def filter_depth(args, scan, produced, rank, world, device):
+class ScanFuser:
+    """--output_type both: the consistency filtering + fusion of a finished scan runs on a WORKER THREAD with its own HIP stream,
+    so the launch thread goes straight on to the next scan's inference (the reference fuses after all inference, single-threaded
+    numpy, eval.py:193-297; round 4 fused every scan synchronously on the launch thread: 0.75 s of fusion stage behind 0.13 s of
+    inference per 49-view scan).  One scan is fused at a time and at most one waits (back-pressure: a rank holds two scans' maps at
+    most).  The per-scan collective (all-gather of the maps) stays on the launch thread -- collectives from two threads would have to
+    agree on an order across ranks -- and the worker itself issues none: per-rank PLY parts are published by rename and rank 0
+    stitches when all of a scan's parts exist.  An exception in the worker is re-raised on the launch thread at the next submit /
+    at close."""
+
+    def __init__(self, args, rank, world, device) -> None:
+        import threading
+        self.args, self.rank, self.world, self.device = args, rank, world, device
+        self.jobs: "queue.Queue" = queue.Queue(maxsize=1)
+        self.error = None
+        self.stream = torch.cuda.Stream(device)
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse")
+        self.state = {}  # buffers that live across scans: the point packer, the pinned rings
+        self.thread = threading.Thread(target=self._run, name="pmn-fuser", daemon=True)
+        self.thread.start()
+
+    def _run(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            if self.error is not None:
+                continue  # drain: the launch thread will see the first error
+            try:
+                with torch.no_grad():
+                    _fuse_scan(self.args, job, self.rank, self.world, self.device, self.stream, self.pool, self.state)
+            except BaseException as e:  # noqa: BLE001 -- handed to the launch thread
+                self.error = e
+
+    def submit(self, job) -> None:
+        if self.error is not None:
+            raise self.error
+        self.jobs.put(job)
+
+    def close(self) -> None:
+        self.jobs.put(None)
+        self.thread.join()
+        self.pool.shutdown(wait=True)
+        if self.error is not None:
+            raise self.error
+
+
+def filter_depth(args, scan, produced, rank, world, device, fuser=None, scan_images=None):
     """Consistency filtering + fusion of one scan (reference eval.py:193-297).  The maps come from device memory (all-gathered
     across ranks) when this run produced them, else from the files a previous --output_type depth run wrote.  Every rank fuses its
-    own block of reference views (pmn_fuse_view, one launch per view); rank 0 stitches the per-rank point lists, which arrive in
-    pair-file order because the blocks are contiguous, into fused.ply."""
+    own block of reference views (pmn_fuse_view + pmn_pack_points per view); rank 0 stitches the per-rank point lists, which arrive
+    in pair-file order because the blocks are contiguous, into fused.ply.  This function is the part that must run on the launch
+    thread (the per-scan all-gather, the map files of views nobody produced); the rest -- ``_fuse_scan`` -- runs right here when
+    ``fuser`` is None, else on the fuser's worker thread while the launch thread goes on to the next scan."""
     pairs = read_pair_file(os.path.join(args.input_folder, scan, "pair.txt"))
     ref_ids = [r for r, _ in pairs]
     view_ids = sorted(set(ref_ids) | {s for _, ss in pairs for s in ss})
@@ -604,54 +663,123 @@ def filter_depth(args, scan, produced, rank, world, device):
         slot_of.update({vid: base + i for i, vid in enumerate(extra)})
     a, b = pdist.block_range(len(pairs), rank, world)
     my_pairs = pairs[a:b]
-    # The host work around the fusion kernel -- decoding the reference image for the point colours, copying the masks / points off
-    # the device, numpy's boolean indexing, three mask PNGs -- is 50-60 ms per 1600x1200 view on one core, 20x the time of the view's
-    # whole inference; all of it releases the GIL, so it runs on a thread pool beside the kernel launches (same files, same bytes).
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(device))  # the gathered buffer is complete once the launch stream gets here
+    job = dict(scan=scan, buf=buf, slot_of=slot_of, cams=cams, sizes=sizes, mixed=mixed, my_pairs=my_pairs, ready=ready,
+               images={ref: (scan_images or {}).get((scan, ref)) for ref, _ in my_pairs})
+    if fuser is not None:
+        fuser.submit(job)
+    else:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse") as pool:
+            _fuse_scan(args, job, rank, world, device, torch.cuda.current_stream(device), pool, {})
+
+
+def _fuse_scan(args, job, rank, world, device, stream, pool, state):
+    """One scan's reference views of this rank: fusion + point packing kernels on ``stream`` (everything stays on the device until
+    the scan's PLY body is complete: ONE contiguous record buffer), the three masks of every view through a ring of pinned buffers
+    to ``pool`` threads that encode the PNGs, the body in 64 MB chunks through pinned memory to pwrite -- the launch thread of this
+    function only enqueues.  Same files, same bytes as the per-view host path of rounds 3-4 (tests/test_eval_gpu.py)."""
+    scan, my_pairs, sizes = job["scan"], job["my_pairs"], job["sizes"]
     t_fuse = time.time()
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "decode_threads", 8), 2), thread_name_prefix="pmn-fuse")
-    def ref_image(r):
+    from patchmatchnet_amd import ops
+    mask_dir = os.path.join(args.output_folder, scan, "mask")
+    os.makedirs(mask_dir, exist_ok=True)
+
+    def ref_image(r):  # a reference view this run did not decode itself (plain DataLoader path, fusion-only run)
         path = os.path.join(args.input_folder, scan, "images/{:0>8}.jpg".format(r))
         u8 = read_image_u8(path, args.image_max_dim)  # the decoded bytes when no down-scaling applies: they are the point colours
-        return u8 if u8 is not None else read_image(path, args.image_max_dim)[0]
+        return u8 if u8 is not None else np.ascontiguousarray(read_image(path, args.image_max_dim)[0], np.float32)
 
-    images = {ref: pool.submit(ref_image, ref) for ref, _ in my_pairs}
-    try:
-        os.makedirs(os.path.join(args.output_folder, scan, "mask"), exist_ok=True)
+    decoding = {ref: pool.submit(ref_image, ref) for ref, _ in my_pairs if job["images"].get(ref) is None}
+    fractions = {}
 
-        def write_masks(ref, masks):  # on the pool thread that finished the view, while later views are still being fused
-            for kind, m in zip(("photo", "geo", "final"), masks):
-                save_image(os.path.join(args.output_folder, scan, "mask/{:0>8}_{}.png".format(ref, kind)), m)
-
-        # returns when every view is fused and its masks are on disk
-        records, _, masks = fusion.fuse_views(buf, slot_of, cams, images, my_pairs, args.geo_pixel_thres, args.geo_depth_thres,
-                                              args.geo_mask_thres, args.photo_thres, sizes=sizes if mixed else None, pool=pool,
-                                              on_view=write_masks, as_records=True)
-        for ref, (photo, geo, final) in masks.items():
+    def write_masks(ref, pin, ev, h, w, ring):
+        try:
+            ev.synchronize()
+            mk = pin.numpy()[:3 * h * w].reshape(3, h, w).view(bool)  # the kernel writes 0 / 1 bytes
+            for kind, m in zip(("photo", "geo", "final"), mk):
+                save_image(os.path.join(mask_dir, "{:0>8}_{}.png".format(ref, kind)), m)
             # count / size = the float64 mean of a bool array the reference prints (eval.py:262-265), without the float64 pass
-            print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
-                os.path.join(args.input_folder, scan), ref, np.count_nonzero(geo) / geo.size, np.count_nonzero(photo) / photo.size,
-                np.count_nonzero(final) / final.size))
-    finally:
-        pool.shutdown(wait=True, cancel_futures=True)
-    ply = os.path.join(args.output_folder, scan, "fused.ply")
-    if world == 1:
-        fusion.write_ply_records(ply, records)
-    else:
-        # per-rank raw vertex records next to the target; rank 0 writes the header for the total and appends the parts in rank
-        # (= pair-file) order: the same bytes a single-rank run writes
-        fusion.write_ply_records(ply + ".part{}".format(rank), records, header=False)
-        torch.distributed.barrier()
+            fractions[ref] = tuple(np.count_nonzero(m) / m.size for m in mk)
+        finally:
+            ring.release(pin)
+
+    with torch.cuda.device(device), torch.cuda.stream(stream):
+        stream.wait_event(job["ready"])
+        capacity = sum(sizes[ref][0] * sizes[ref][1] for ref, _ in my_pairs)
+        packer = state.get("packer")
+        if packer is None or packer.capacity < capacity or packer.view_counts.numel() < len(my_pairs):
+            state.pop("packer", None)
+            packer = state["packer"] = ops.PointPacker(max(capacity, 1), device, max_views=max(len(my_pairs), 64))
+        packer.reset()
+        hmax = max([sizes[ref][0] * sizes[ref][1] for ref, _ in my_pairs] or [1])
+        mring = state.get("mask_ring")
+        if mring is None or mring.nbytes < 3 * hmax:
+            mring = state["mask_ring"] = fusion.PinnedRing(3 * hmax, 8)
+        bring = state.get("body_ring")
+        if bring is None:
+            bring = state["body_ring"] = fusion.PinnedRing(64 << 20, 4)
+
+        class Images(dict):  # uploads a host-decoded image the moment its view is fused
+            def __missing__(self, ref):
+                arr = decoding[ref].result()
+                self[ref] = torch.from_numpy(arr).to(device)
+                return self[ref]
+
+        images = Images({ref: im for ref, im in job["images"].items() if im is not None})
+        pending = []
+        for ref, m in fusion.fuse_views_packed(job["buf"], job["slot_of"], job["cams"], images, my_pairs, args.geo_pixel_thres,
+                                               args.geo_depth_thres, args.geo_mask_thres, args.photo_thres, packer,
+                                               sizes=sizes if job["mixed"] else None):
+            h, w = sizes[ref]
+            pin = mring.acquire()  # blocks while eight views' masks are still being encoded
+            pin[:3 * h * w].copy_(m.reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            pending.append(pool.submit(write_masks, ref, pin, ev, h, w, mring))
+            images.pop(ref, None)
+        counts = packer.counts()  # the only synchronisation with the device: every view's number of points
+        total = sum(counts)
+        ply = os.path.join(args.output_folder, scan, "fused.ply")
+        target = ply if world == 1 else ply + ".part{}.tmp".format(rank)
+        header = fusion.ply_header(total) if world == 1 else b""
+        fd = os.open(target, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            if header:
+                os.pwrite(fd, header, 0)
+            pending += fusion.download_to_file(packer.records, 15 * total, fd, len(header), bring, pool, stream)
+            for f in pending:
+                f.result()  # re-raises a writer's exception
+        finally:
+            os.close(fd)
+    for ref, _ in my_pairs:
+        photo, geo, final = fractions[ref]
+        print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
+            os.path.join(args.input_folder, scan), ref, geo, photo, final))
+    if world > 1:
+        # per-rank raw vertex records next to the target, published by rename; rank 0 writes the header for the total and appends the
+        # parts in rank (= pair-file) order when all of them exist: the same bytes a single-rank run writes.  No collective here:
+        # this may be a worker thread (main() removed stale parts of an earlier run behind a barrier before the first scan).
+        os.replace(target, ply + ".part{}".format(rank))
         if rank == 0:
             parts = [ply + ".part{}".format(r) for r in range(world)]
-            total = sum(os.path.getsize(p) for p in parts) // 15
+            deadline = time.time() + 3600.0
+            while not all(os.path.exists(p) for p in parts):
+                if time.time() > deadline:
+                    raise P.PmnError("{}: the point lists of the other ranks never arrived ({})".format(scan, parts))
+                time.sleep(0.005)
+            n_points = sum(os.path.getsize(p) for p in parts) // 15
             with open(ply, "wb") as f:
-                f.write(fusion.ply_header(total))
+                f.write(fusion.ply_header(n_points))
                 for p in parts:
                     with open(p, "rb") as g:
-                        f.write(g.read())
+                        while True:
+                            chunk = g.read(64 << 20)
+                            if not chunk:
+                                break
+                            f.write(chunk)
             for p in parts:
                 os.remove(p)
-        torch.distributed.barrier()
     if rank == 0:
         print("saving the final model to", ply)
     print("fusion stage: {} reference views of {} in {:.3f} s on this rank".format(len(my_pairs), scan or args.input_folder,
@@ -702,6 +830,11 @@ def build_parser():
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
                         "(-1 = one RNG stream per process, like the reference)")
     p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
+    p.add_argument("--fuse_threads", type=int, default=8,
+                   help="threads of the fusion stage: mask PNG encoding, reference images the run did not decode itself, fused.ply chunks")
+    p.add_argument("--fuse_async", type=int, default=1,
+                   help="--output_type both: 1 = a finished scan is filtered + fused on a worker thread with its own HIP stream while "
+                        "the next scan's inference runs; 0 = inline on the launch thread (same files, same bytes)")
     p.add_argument("--in_flight", type=int, default=2,
                    help="samples in flight per GPU (HIP streams, one graph-replay slot each); needs --hip_graph 1")
     p.add_argument("--hip_graph", type=int, default=1,
@@ -713,6 +846,15 @@ def build_parser():
                    help="> 0: decode and encode every view of a scan ONCE per rank and keep its FeatureNet pyramid on the device "
                         "(0 = re-decode and re-encode per sample like the reference; needs --batch_size 1)")
     return p
+
+
+def _scan_names(args):
+    if args.scan_list:
+        if not os.path.isfile(args.scan_list):
+            raise Exception("Invalid scan list file: {}".format(args.scan_list))
+        with open(args.scan_list) as f:
+            return [ln.rstrip() for ln in f.readlines()]
+    return [""]
 
 
 def main(argv=None):
@@ -736,21 +878,46 @@ def main(argv=None):
         args.num_workers = max(min(share - 2, 8), 2)
     if args.decode_threads < 0:  # decode THREADS of the encode-once path
         args.decode_threads = max(min(share - 2, 8), 2)  # measured: 8 threads 256-262 depth-maps/s, 32: 242, 64: 195 (GIL)
+    if _DISCARD_MAPS:  # a measurement aid (scripts/eval_bench.py), never silent: the run reports every iteration and writes no map
+        print("WARNING: PMN_EVAL_DISCARD_MAPS=1 -- depth / confidence maps are computed and downloaded but NOT written to disk")
+        if args.output_type != "depth":
+            raise Exception("PMN_EVAL_DISCARD_MAPS=1 is a timing aid for --output_type depth only")
+    if args.output_type != "depth" and world > 1:
+        # per-rank point lists are published as <scan>/fused.ply.part<rank> (see _fuse_scan): parts an interrupted earlier run left
+        # behind must be gone before anybody starts waiting for this run's
+        for scan in _scan_names(args):
+            for name in ("fused.ply.part{}".format(rank), "fused.ply.part{}.tmp".format(rank)):
+                stale = os.path.join(args.output_folder, scan, name)
+                if os.path.exists(stale):
+                    os.remove(stale)
+        torch.distributed.barrier()
     if args.output_type == "depth":
         save_depth(args, rank, world, device)
     elif args.output_type == "both":
-        # every scan is fused as soon as its maps exist, straight from device memory (the per-scan all-gather)
-        save_depth(args, rank, world, device,
-                   on_scan_done=lambda scan, produced: filter_depth(args, scan, produced, rank, world, device))
+        # every scan is fused as soon as its maps exist, straight from device memory (the per-scan all-gather), on a worker thread
+        # with its own stream while the launch thread infers the next scan (--fuse_async 0: inline, rounds 3-4's order)
+        fuser = ScanFuser(args, rank, world, device) if args.fuse_async else None
+        scan_images = {}
+        try:
+            save_depth(args, rank, world, device, scan_images=scan_images,
+                       on_scan_done=lambda scan, produced: filter_depth(args, scan, produced, rank, world, device, fuser=fuser,
+                                                                        scan_images=scan_images))
+        except BaseException:
+            if fuser is not None:
+                try:
+                    fuser.close()
+                except BaseException:  # noqa: BLE001 -- the first error is the one to report
+                    pass
+            raise
+        if fuser is not None:
+            t_wait = time.time()
+            fuser.close()  # the last scan(s) may still be in the fusion stage
+            print("fusion of the last scan(s) finished {:.3f} s after the depth stage".format(time.time() - t_wait))
+        n_maps, t_loaded = args._depth_stage
+        print("both stages: {} depth maps inferred, filtered and fused in {:.3f} s -> {:.1f} depth-maps/s on this rank (masks and "
+              "fused.ply on disk; model load excluded)".format(n_maps, time.time() - t_loaded, n_maps / max(time.time() - t_loaded, 1e-9)))
     else:
-        if args.scan_list:
-            if not os.path.isfile(args.scan_list):
-                raise Exception("Invalid scan list file: {}".format(args.scan_list))
-            with open(args.scan_list) as f:
-                scans = [ln.rstrip() for ln in f.readlines()]
-        else:
-            scans = [""]
-        for scan in scans:
+        for scan in _scan_names(args):
             filter_depth(args, scan, None, rank, world, device)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

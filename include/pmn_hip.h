@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 18
+#define PMN_ABI_VERSION 19
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -277,6 +277,19 @@ int pmn_differentiable_warping(const float *src_nchw, const float *rel_proj, con
 int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const int *src_slots_host,
                   const int *src_hw_host, int n_src, const float *mats, int H, int W, float geo_pixel_thres, float geo_depth_thres, int geo_mask_thres,
                   float photo_thres, unsigned char *masks, float *xyz, double *depth_avg, int *geo_sum, void *stream);
+
+/* ABI 19.  The point list of one fused reference view as PLY vertex records, packed on the device (reference eval.py:270-281: the
+ * valid pixels' world points and colours, row-major; :283-297: plyfile's vertex element = x, y, z little-endian float32 + red,
+ * green, blue uint8 = 15 bytes).  final_mask [H][W] bytes and xyz [H][W][3] are pmn_fuse_view's outputs; image_hwc [H][W][3] is
+ * the reference view's image, uint8 as decoded (image_is_float = 0: the bytes are the colours) or float32 in [0,1]
+ * (image_is_float = 1: (unsigned char)(f * 255.0f), the reference's (color * 255).astype(uint8)).  The records of the pixels whose
+ * mask byte is non-zero are APPENDED to `records` (device bytes, room for capacity_points records) at record index *cursor
+ * (DEVICE int64), in row-major pixel order; then *cursor += count and *view_count (DEVICE int32) = count.  If the view does not
+ * fit, nothing is written, the cursor stays and *view_count = -1.  scratch: DEVICE int64[ceil(H*W / 1024)].  Three launches on
+ * `stream`; consecutive calls on one stream append view after view -- a scan's whole PLY body as one device buffer. */
+int pmn_pack_points(const unsigned char *final_mask, const float *xyz, const void *image_hwc, int image_is_float, int H, int W,
+                    unsigned char *records, long long capacity_points, long long *cursor, int *view_count, long long *scratch,
+                    void *stream);
 
 
 #ifdef __cplusplus

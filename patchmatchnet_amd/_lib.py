@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -55,6 +55,7 @@ SIGNATURES = {
     "pmn_stem_f16s_views": [_fp, _i] + [_fp] * 5 + [_i] * 3 + [_s],
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
     "pmn_fuse_view": [_fp, ctypes.c_longlong, _i, _hp, _hp, _i, _fp, _i, _i, _f, _f, _i, _f, _fp, _fp, _fp, _ip, _s],
+    "pmn_pack_points": [_fp, _fp, _fp, _i, _i, _i, _fp, ctypes.c_longlong, _fp, _ip, _fp, _s],
 }
 
 # libpmn_hip_experimental.so only (include/pmn_hip_experimental.h; `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`)

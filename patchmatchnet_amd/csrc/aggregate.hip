@@ -16,6 +16,11 @@
 #include <cstring>
 
 #include "pmn_common.hpp"
+#ifdef PMN_ATEN_GPU_DIV  // attribution build: index / (D - 1) as ATen's GPU kernel takes it, index * (1.0f / (D - 1))
+#define PMN_DIV_DM1(acc, D) ((acc) * (1.0f / (float)((D) - 1)))
+#else
+#define PMN_DIV_DM1(acc, D) ((acc) / (float)((D) - 1))
+#endif
 
 struct AggArgs {
     const float* cost;     // [B,h,w,D]
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     if (a.is_inverse) {
         const float inv_min = 1.0f / a.depth[((size_t)b * D + (D - 1)) * hw + p];
         const float inv_max = 1.0f / a.depth[((size_t)b * D) * hw + p];
-        const float inv = inv_max + acc / (float)(D - 1) * (inv_min - inv_max);
+        const float inv = inv_max + PMN_DIV_DM1(acc, D) * (inv_min - inv_max);
         out = 1.0f / inv;
     }
     a.depth_out[(size_t)b * hw + p] = out;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     if (a.is_inverse) {
         const float inv_min = 1.0f / a.depth[((size_t)b * D + (D - 1)) * hw + p];
         const float inv_max = 1.0f / a.depth[((size_t)b * D) * hw + p];
-        const float inv = inv_max + acc / (float)(D - 1) * (inv_min - inv_max);
+        const float inv = inv_max + PMN_DIV_DM1(acc, D) * (inv_min - inv_max);
         out = 1.0f / inv;
     }
     a.depth_out[(size_t)b * hw + p] = out;

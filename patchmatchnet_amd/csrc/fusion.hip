@@ -153,3 +153,149 @@ extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_s
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
+
+// ---- point packing (round 5) --------------------------------------------------------------------------------------------
+// The host half of reference eval.py:270-281 on the device: the pixels that survive the final mask become PLY vertex records
+// (x, y, z little-endian float32 + red, green, blue uint8: the 15 bytes plyfile writes per vertex, eval.py:283-297) in row-major
+// pixel order, appended to a per-scan record buffer at a device-resident cursor -- so a scan's fused.ply body is ONE contiguous
+// device buffer that leaves through pinned memory in large chunks, instead of per view: boolean index on the device (a
+// synchronising nonzero), two variable-size downloads, numpy's boolean index of the reference image and two strided byte copies.
+// Three launches per view on the caller's stream: per-block counts (1024 pixels per block), an exclusive scan of the block counts
+// that also advances the cursor, and the pack.  Colours: the decoded image bytes (uint8 [H,W,3]), or for a resized float image in
+// [0,1] the reference's (color * 255).astype(uint8) = truncation of the float32 product.
+#define PMN_PACK_PIX 4                        // consecutive pixels per thread
+#define PMN_PACK_BLOCK (256 * PMN_PACK_PIX)   // pixels per workgroup
+
+__device__ __forceinline__ int pack_flags(const unsigned char* __restrict__ mask, long long p0, long long n, bool (&keep)[PMN_PACK_PIX]) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < PMN_PACK_PIX; ++j) {
+        keep[j] = (p0 + j < n) && mask[p0 + j] != 0;
+        c += keep[j] ? 1 : 0;
+    }
+    return c;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pack_count_kernel(const unsigned char* __restrict__ mask, long long n, long long* __restrict__ blocks) {
+    __shared__ int part[4];
+    bool keep[PMN_PACK_PIX];
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * PMN_PACK_PIX;
+    const int c = wave_sum(pack_flags(mask, p0, n, keep));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blocks[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// blocks[i] (counts) -> absolute record index of block i's first point; *cursor += total unless the buffer would overflow
+// (then the view's count is reported as -1 and nothing is packed)
+__global__ __launch_bounds__(1024) void pack_scan_kernel(long long* __restrict__ blocks, int nblocks, long long* __restrict__ cursor,
+                                                         long long capacity, int* __restrict__ view_count) {
+    __shared__ long long tmp[1024];
+    __shared__ long long carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    const long long base = *cursor;
+    for (int c0 = 0; c0 < nblocks; c0 += 1024) {
+        const int i = c0 + t;
+        const long long mine = i < nblocks ? blocks[i] : 0;
+        tmp[t] = mine;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+            const long long add = t >= o ? tmp[t - o] : 0;
+            __syncthreads();
+            tmp[t] += add;
+            __syncthreads();
+        }
+        const long long incl = tmp[t], before = carry;
+        if (i < nblocks) blocks[i] = base + before + incl - mine;
+        __syncthreads();
+        if (t == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const long long total = carry;
+        if (base + total > capacity) {
+            *view_count = -1;
+            blocks[0] = -1;  // the pack launch reads this flag
+        } else {
+            *view_count = (int)total;
+            *cursor = base + total;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_write_kernel(const unsigned char* __restrict__ mask, const float* __restrict__ xyz,
+                                                         const void* __restrict__ image, int image_is_float, long long n,
+                                                         const long long* __restrict__ blocks, unsigned char* __restrict__ records) {
+#pragma clang fp contract(off)
+    __shared__ int part[4];
+    if (blocks[0] < 0) return;  // overflow reported by the scan
+    bool keep[PMN_PACK_PIX];
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * PMN_PACK_PIX;
+    const int c = pack_flags(mask, p0, n, keep);
+    // exclusive prefix of c over the workgroup's threads (= row-major pixel order): inclusive scan inside the wave, wave totals via LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    int before = incl - c;
+    for (int k = 0; k < wv; ++k) before += part[k];
+    long long r = blocks[blockIdx.x] + before;
+#pragma unroll
+    for (int j = 0; j < PMN_PACK_PIX; ++j) {
+        if (!keep[j]) continue;
+        const long long p = p0 + j;
+        unsigned int word[4];
+        word[0] = __float_as_uint(xyz[3 * p + 0]);
+        word[1] = __float_as_uint(xyz[3 * p + 1]);
+        word[2] = __float_as_uint(xyz[3 * p + 2]);
+        unsigned int cr, cg, cb;
+        if (image_is_float) {
+            const float* im = static_cast<const float*>(image) + 3 * p;
+            cr = (unsigned char)(im[0] * 255.0f);
+            cg = (unsigned char)(im[1] * 255.0f);
+            cb = (unsigned char)(im[2] * 255.0f);
+        } else {
+            const unsigned char* im = static_cast<const unsigned char*>(image) + 3 * p;
+            cr = im[0];
+            cg = im[1];
+            cb = im[2];
+        }
+        word[3] = cr | (cg << 8) | (cb << 16);
+        unsigned char* o = records + r * 15;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) o[i] = (unsigned char)(word[i >> 2] >> (8 * (i & 3)));
+        ++r;
+    }
+}
+
+extern "C" int pmn_pack_points(const unsigned char* final_mask, const float* xyz, const void* image_hwc, int image_is_float, int H,
+                               int W, unsigned char* records, long long capacity_points, long long* cursor, int* view_count,
+                               long long* scratch, void* stream) {
+    if (!final_mask || !xyz || !image_hwc || !records || !cursor || !view_count || !scratch) return PMN_ERR_ARG;
+    if (H < 1 || W < 1 || capacity_points < 0) return PMN_ERR_ARG;
+    const long long n = (long long)H * W;
+    const long long nb = (n + PMN_PACK_BLOCK - 1) / PMN_PACK_BLOCK;
+    if (nb > 0x7fffffffLL) return PMN_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, n, scratch);
+    PMN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, scratch, (int)nb, cursor, capacity_points, view_count);
+    PMN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pack_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, xyz, image_hwc, image_is_float, n,
+                       (const long long*)scratch, records);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

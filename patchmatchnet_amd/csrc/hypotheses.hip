@@ -9,6 +9,13 @@
 #include <cstring>
 
 #include "pmn_common.hpp"
+#ifdef PMN_ATEN_GPU_DIV  // attribution build: u / 48 as ATen's GPU kernel takes it, u * (1.0f / 48.0f)
+#define PMN_DIV48(u) ((u) * (1.0f / 48.0f))
+#define PMN_DIV48R(u) ((u) * (1.0f / 48.0f))
+#else
+#define PMN_DIV48(u) ((u) / 48.0f)
+#define PMN_DIV48R(u) pmn_div_by((u), 48.0f, r48)
+#endif
 
 struct HypArgs {
     const float* noise;      // [B,48,h,w] or null
@@ -30,7 +37,7 @@ __device__ __forceinline__ float centre_hypothesis(const HypArgs& a, int b, int 
     const int h = a.h, w = a.w;
     if (a.noise) {
         const float u = a.noise[((size_t)b * 48 + 24) * h * w + (size_t)qy * w + qx] + 24.0f;
-        const float inv = inv_max + u / 48.0f * (inv_min - inv_max);
+        const float inv = inv_max + PMN_DIV48(u) * (inv_min - inv_max);
         return 1.0f / inv;
     }
     const int ws = w >> a.depth_shift;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_kernel(const HypArg
         for (int j = 0; j < 48; ++j) {
             if (j < NP2) {
                 const float u = a.noise[((size_t)b * 48 + j) * hw + p] + (float)j;
-                const float inv = inv_max + u / 48.0f * (inv_min - inv_max);
+                const float inv = inv_max + PMN_DIV48(u) * (inv_min - inv_max);
                 v[j] = 1.0f / inv;
             }
         }
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
         for (int j = 0; j < D0T; ++j) u[j] = a.noise[((size_t)b * 48 + j) * hw + p];
 #pragma unroll
         for (int j = 0; j < D0T; ++j) {
-            const float inv = inv_max + pmn_div_by(u[j] + (float)j, 48.0f, r48) * (inv_min - inv_max);
+            const float inv = inv_max + PMN_DIV48R(u[j] + (float)j) * (inv_min - inv_max);
             v[j] = pmn_div(1.0f, inv);
         }
     } else {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(PMN_BLOCK) void init_hypotheses_fixed_kernel(const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (from_noise) {
-                        const float inv = inv_max + pmn_div_by(c[i][q] + 24.0f, 48.0f, r48) * (inv_min - inv_max);
+                        const float inv = inv_max + PMN_DIV48R(c[i][q] + 24.0f) * (inv_min - inv_max);
                         cc[q] = pmn_div(1.0f, inv);
                     } else if (a.num_sample == 1) {
                         cc[q] = c[i][q];

@@ -171,7 +171,11 @@ __device__ __forceinline__ bool pmn_pose_position(const PmnPose& q, float d, int
     }
     const float rz = pmn_rcp_refined(pz);
     const float gx = pmn_div_by(px, pz, rz), gy = pmn_div_by(py, pz, rz);                  // proj_xyz[:, :2] / z
+#ifdef PMN_ATEN_GPU_DIV  // attribution build: ATen's GPU division by a host scalar is a multiplication by the rounded reciprocal
+    const float xn = gx * pmn_uniform(pmn_div(1.0f, q.cx)) - 1.0f, yn = gy * pmn_uniform(pmn_div(1.0f, q.cy)) - 1.0f;
+#else
     const float xn = pmn_div_by(gx, q.cx, q.rcx) - 1.0f, yn = pmn_div_by(gy, q.cy, q.rcy) - 1.0f;  // x / ((w - 1) / 2) - 1
+#endif
     ix = pmn_unnorm_align(xn, ws);
     iy = pmn_unnorm_align(yn, hs);
     return front;
@@ -194,8 +198,13 @@ __device__ __forceinline__ void pmn_neighbor_position(float x, float y, int dy, 
     const float rcx = pmn_uniform(pmn_rcp_refined(cx)), rcy = pmn_uniform(pmn_rcp_refined(cy));  // loop-invariant, in SGPRs
     float X = x + ((float)dx + offx);
     float Y = y + ((float)dy + offy);
+#ifdef PMN_ATEN_GPU_DIV
+    float xn = X * pmn_uniform(pmn_div(1.0f, cx)) - 1.0f;
+    float yn = Y * pmn_uniform(pmn_div(1.0f, cy)) - 1.0f;
+#else
     float xn = pmn_div_by(X, cx, rcx) - 1.0f;
     float yn = pmn_div_by(Y, cy, rcy) - 1.0f;
+#endif
     ix = fminf(fmaxf(pmn_unnorm_noalign(xn, w), 0.0f), (float)(w - 1));
     iy = fminf(fmaxf(pmn_unnorm_noalign(yn, h), 0.0f), (float)(h - 1));
 }

@@ -170,3 +170,76 @@ def write_ply_records(filename: str, chunks, header: bool = True) -> int:
         for c in chunks:
             c.tofile(f)
     return total
+
+
+# ---- round 5: the scan's PLY body packed on the device -----------------------------------------------------------------------
+
+def fuse_views_packed(maps: torch.Tensor, slot_of: Dict[int, int], cams: Dict[int, Dict], images: Dict[int, torch.Tensor],
+                      pairs: List[Tuple[int, List[int]]], geo_pixel_thres: float, geo_depth_thres: float, geo_mask_thres: int,
+                      photo_thres: float, packer: "ops.PointPacker", sizes: Optional[Dict[int, Tuple[int, int]]] = None):
+    """The device half of ``fuse_views`` and nothing else: per reference view of ``pairs`` one pmn_fuse_view launch and one
+    pmn_pack_points (three small launches) on the CURRENT stream -- the kept points become PLY vertex records appended to
+    ``packer.records`` in pair-file / row-major order (reference eval.py:270-297), nothing synchronises, nothing leaves the device.
+    ``images[ref]``: the reference view's image ON THE DEVICE, [H,W,3] uint8 (the decoded bytes) or float32 in [0,1].
+    A generator: yields (ref, masks) per view -- masks = the [3,H,W] uint8 device tensor (photo, geo, final) -- so that the caller
+    can queue its download behind the launches.  After the last view ``packer.counts()`` holds every view's number of points."""
+    if not maps.is_cuda:
+        raise PmnError("fusion runs on a ROCm GPU only (pmn_fuse_view); there is no CPU fallback")
+    slot_sizes = None
+    if sizes is not None:
+        slot_sizes = [(1, 1)] * maps.shape[0]
+        for vid, sl in slot_of.items():
+            slot_sizes[sl] = tuple(sizes[vid])
+    for ref, srcs in pairs:
+        block = camera_block(cams[ref]["intrinsics"], cams[ref]["extrinsics"],
+                             [(cams[s]["intrinsics"], cams[s]["extrinsics"]) for s in srcs])
+        mats = torch.from_numpy(block).to(maps.device)
+        m, xyz, _, _ = ops.fuse_view(maps, slot_of[ref], [slot_of[s] for s in srcs], mats, geo_pixel_thres, geo_depth_thres,
+                                     geo_mask_thres, photo_thres, sizes=slot_sizes)
+        packer.append(m[2], xyz, images[ref])
+        yield ref, m
+
+
+class PinnedRing:
+    """A few pinned host buffers of one size handed out round-robin; ``acquire`` blocks until the buffer's previous user called
+    ``release`` (back-pressure for a download -> write pipeline whose consumers are pool threads)."""
+
+    def __init__(self, nbytes: int, count: int) -> None:
+        import queue
+        self.nbytes = int(nbytes)
+        self.free: "queue.Queue[torch.Tensor]" = queue.Queue()
+        for _ in range(count):
+            self.free.put(torch.empty((self.nbytes,), dtype=torch.uint8).pin_memory())
+
+    def acquire(self) -> torch.Tensor:
+        return self.free.get()
+
+    def release(self, buf: torch.Tensor) -> None:
+        self.free.put(buf)
+
+
+def download_to_file(src: torch.Tensor, nbytes: int, fd: int, file_offset: int, ring: PinnedRing, pool, stream) -> list:
+    """``src[:nbytes]`` (device uint8) -> the open file ``fd`` at ``file_offset``: chunks of the ring's buffer size are copied into
+    pinned memory on ``stream`` and written by ``pool`` threads with pwrite at their own offsets (the copy of chunk k+1 overlaps the
+    write of chunk k; several writes run at once; os.pwrite releases the GIL).  Returns the write futures."""
+    futures, done = [], 0
+    while done < nbytes:
+        n = min(ring.nbytes, nbytes - done)
+        buf = ring.acquire()
+        with torch.cuda.stream(stream):
+            buf[:n].copy_(src[done:done + n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+
+        def write(buf=buf, n=n, at=file_offset + done, ev=ev):
+            try:
+                ev.synchronize()
+                mv, put = memoryview(buf.numpy())[:n], 0
+                while put < n:
+                    put += os.pwrite(fd, mv[put:], at + put)
+            finally:
+                ring.release(buf)
+
+        futures.append(pool.submit(write))
+        done += n
+    return futures

@@ -802,3 +802,56 @@ def fuse_view(maps: torch.Tensor, ref_slot: int, src_slots: Sequence[int], mats:
               "pmn_fuse_view")
     del slots, hw
     return masks, xyz, davg, gsum
+
+
+class PointPacker:
+    """pmn_pack_points: the PLY vertex records of a scan's fused reference views, packed on the device view after view into ONE
+    record buffer (reference eval.py:270-297).  ``capacity`` = room in points (a view can keep at most H*W).
+
+        packer = PointPacker(capacity, device)
+        for every reference view:  packer.append(masks[2], xyz, image_hwc)        # three launches on the current stream
+        counts = packer.counts()                                                   # synchronises the current stream
+        body = packer.records[:15 * sum(counts)]                                   # device uint8: the PLY body in pair-file order
+    """
+
+    def __init__(self, capacity: int, device, max_views: int = 1024) -> None:
+        self.capacity = int(capacity)
+        self.records = torch.empty((15 * self.capacity,), dtype=torch.uint8, device=device)
+        self.cursor = torch.zeros((1,), dtype=torch.int64, device=device)
+        self.view_counts = torch.zeros((max_views,), dtype=torch.int32, device=device)
+        self.scratch = None
+        self.n = 0
+
+    def reset(self) -> None:
+        self.cursor.zero_()
+        self.n = 0
+
+    def append(self, final_mask: torch.Tensor, xyz: torch.Tensor, image_hwc: torch.Tensor) -> None:
+        _dev(final_mask, "final_mask")
+        _dev(xyz, "xyz")
+        _dev(image_hwc, "image_hwc")
+        H, W = final_mask.shape
+        if final_mask.dtype != torch.uint8 or not final_mask.is_contiguous():
+            raise PmnError("pack_points: final_mask must be contiguous uint8 [H,W]")
+        if tuple(xyz.shape) != (H, W, 3) or xyz.dtype != torch.float32 or not xyz.is_contiguous():
+            raise PmnError("pack_points: xyz must be contiguous float32 [H,W,3]")
+        if tuple(image_hwc.shape) != (H, W, 3) or image_hwc.dtype not in (torch.uint8, torch.float32) or not image_hwc.is_contiguous():
+            raise PmnError("pack_points: image must be contiguous uint8 or float32 [H,W,3]")
+        if self.n >= self.view_counts.numel():
+            raise PmnError("pack_points: more views than the packer was sized for")
+        nb = (H * W + 1023) // 1024
+        if self.scratch is None or self.scratch.numel() < nb:
+            self.scratch = torch.empty((nb,), dtype=torch.int64, device=self.records.device)
+        with torch.cuda.device(self.records.device):
+            check(_lib.lib().pmn_pack_points(final_mask.data_ptr(), xyz.data_ptr(), image_hwc.data_ptr(),
+                                             1 if image_hwc.dtype == torch.float32 else 0, H, W, self.records.data_ptr(),
+                                             self.capacity, self.cursor.data_ptr(), self.view_counts[self.n:].data_ptr(),
+                                             self.scratch.data_ptr(), _stream(self.records)), "pmn_pack_points")
+        self.n += 1
+
+    def counts(self):
+        """Per-view point counts (host list); raises if a view did not fit."""
+        c = self.view_counts[:self.n].cpu().tolist()
+        if any(x < 0 for x in c):
+            raise PmnError("pack_points: the record buffer is too small for this scan")
+        return c

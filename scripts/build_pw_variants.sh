@@ -30,3 +30,11 @@ wait
 ( /opt/rocm/bin/hipcc $FLAGS -DPMN_POSE_FMA -c $CS/gather_corr.hip -o build/pw/gather_corr_posefma.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_posefma.so build/pw/gather_corr_posefma.o $OTHERS
   echo "built build/pw/libpmn_hip_posefma.so" )
+# attribution build: ATen's GPU division by a host scalar (x * (1/c)) in the normalisations, u/48 and index/(D-1) (-DPMN_ATEN_GPU_DIV)
+( objs=""
+  for f in gather_corr aggregate hypotheses misc; do
+    /opt/rocm/bin/hipcc $FLAGS -DPMN_ATEN_GPU_DIV -c $CS/$f.hip -o build/pw/${f}_atendiv.o; objs="$objs build/pw/${f}_atendiv.o"
+  done
+  rest=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v 'gather_corr.o\|aggregate.o\|hypotheses.o\|misc.o')
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_atendiv.so $objs $rest
+  echo "built build/pw/libpmn_hip_atendiv.so" )

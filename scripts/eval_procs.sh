@@ -15,9 +15,11 @@ for s in range(6, 24):
     shutil.copytree(os.path.join(data, "scan%d" % (s % 6 + 1)), os.path.join(data, "scan%d" % (s + 1)))
 open(os.path.join(data, "list.txt"), "w").write("".join("scan%d\n" % (s + 1) for s in range(24)))
 PY
-for i in 1 2 3 4 5 6; do
+OUTPUT_TYPE=${OUTPUT_TYPE:-depth}   # both: inference + consistency filtering + fusion (masks, fused.ply), the reference's default
+RUNS=${RUNS:-1 2 3 4 5 6}
+for i in $RUNS; do
   extra=""; [ $i -ge 5 ] && extra="$EXTRA_ENV"
   rm -rf $B/out
-  env $extra python eval.py --input_folder $B/data --output_folder $B/out --checkpoint_path tests/golden/params_000007.npz --scan_list $B/data/list.txt --num_views 5 --file_format .pfm --output_type depth 2>&1 | grep -E "depth stage|bound to" | sed "s/^/run $i $extra: /"
-done | tee gpurun_out/eval_procs.log
+  env $extra python eval.py --input_folder $B/data --output_folder $B/out --checkpoint_path tests/golden/params_000007.npz --scan_list $B/data/list.txt --num_views 5 --file_format .pfm --output_type $OUTPUT_TYPE --geo_mask_thres 3 $EVAL_EXTRA 2>&1 | grep -E "depth stage|both stages|fusion of the last|bound to|Error|error" | sed "s/^/run $i $extra: /"
+done | tee gpurun_out/eval_procs_$OUTPUT_TYPE.log
 rm -rf $B

@@ -418,6 +418,34 @@ def test_cfg2_scene_against_the_reference_on_rocm():
            "B_vs_A_reference_cpu_gpu_floor": {k: stats(B[k], A[k]) for k in A},
            "C_vs_A": {k: stats(C[k], A[k]) for k in A}, "C_vs_B": {k: stats(C[k], B[k]) for k in A},
            "D_vs_B_cascade_only": {k: stats(D[k], B[k]) for k in A}}
+    # ---- F: IDENTICAL INPUTS at every stage boundary: the reference's stage modules on ROCm are handed THIS ENGINE's previous-stage
+    # depth and view weights (nearest x2, models/net.py:272-275), B's features and torch-on-ROCm projections (models/net.py:225-231);
+    # iteration 1 of every stage and the refinement are then one call of each side on the same tensors -- the north star's "identical
+    # inputs" clause against the GPU path, strictly on every pixel; iteration 2 has one free step inside the stage.
+    Fn = torch.nn.functional
+    Kd, Ed = t(intr), t(extr)
+    vw_engine = d_dbg[3][0]["view_weights"]
+    depth_in, vw_in = torch.empty(0, device=DEV), torch.empty(0, device=DEV)
+    forced, scale = {}, 0.125
+    with torch.no_grad():
+        for stage in (3, 2, 1):
+            Ks = Kd.clone()
+            Ks[:, :, :2] *= scale
+            proj = Ed.clone()
+            proj[:, :, :3, :4] = torch.matmul(Ks, Ed[:, :, :3, :4])
+            pl = torch.unbind(proj, 1)
+            scale *= 2.0
+            depths, _, _ = getattr(ref, f"patchmatch_{stage}")(
+                ref_feature=b_feats[0][stage], src_features=[f[stage] for f in b_feats[1:]], ref_proj=pl[0], src_projs=list(pl[1:]),
+                depth_min=dmin, depth_max=dmax, depth=depth_in, view_weights=vw_in)
+            for it, d in enumerate(depths):
+                forced[f"s{stage}_it{it + 1}"] = stats(n(d_dpm[stage][it]), n(d))
+            if stage > 1:
+                depth_in = Fn.interpolate(d_dpm[stage][-1].detach(), scale_factor=2.0, mode="nearest")
+                vw_in = Fn.interpolate(vw_engine if stage == 3 else vw_in, scale_factor=2.0, mode="nearest")
+        forced["final"] = stats(n(d_depth), n(ref.upsample_net(dimgs[0], d_dpm[1][-1].detach(), dmin, dmax)))
+    torch.cuda.synchronize()
+    rep["F_identical_inputs_at_every_stage_boundary"] = forced
     # FeatureNet backends against each other (relative to each map's scale): MIOpen (B) vs this engine's HIP convolutions
     rep["featurenet_hip_vs_miopen_rel_to_scale"] = {
         f"s{s}": float(max(((own[v][s] - b_feats[v][s]).abs().max() / b_feats[v][s].abs().max()).item() for v in range(nv)))
@@ -431,6 +459,9 @@ def test_cfg2_scene_against_the_reference_on_rocm():
         json.dump(rep, f, indent=1)
     _report(test="cfg2_scene_vs_reference_on_rocm", **{k: v for k, v in rep.items() if k not in ("what", "legs")})
 
+    # identical inputs: the north star's 1e-3 on EVERY pixel, against the reference's GPU path
+    for k in ("s3_it1", "s2_it1", "s1_it1", "final"):
+        assert forced[k]["max"] < 1e-3, (k, forced[k])
     dvb, floor_all = rep["D_vs_B_cascade_only"], rep["B_vs_A_reference_cpu_gpu_floor"]
     # the first Evaluation has no history to amplify: strict, as against the CPU golden (measured 4.7e-6; the reference's own
     # CPU<->GPU difference there: 6.0e-6)

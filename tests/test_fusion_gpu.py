@@ -127,3 +127,68 @@ def test_fuse_scan_on_a_consistent_scene_incl_mixed_view_sizes(mixed):
     if same:
         assert np.abs(v - vo).max() / np.abs(vo).max() < 1e-6
         np.testing.assert_array_equal(c, co)
+
+
+@pytest.mark.parametrize("mixed,float_images", [(False, False), (False, True), (True, True)])
+def test_packed_records_are_the_host_paths_bytes(mixed, float_images, tmp_path):
+    """pmn_pack_points (round 5): the scan's PLY body packed on the device view after view == the per-view host path of rounds 3-4
+    (boolean index on the device, numpy's boolean index of the image, fusion.ply_records), BYTE FOR BYTE -- reference
+    eval.py:270-297: valid pixels row-major, x y z float32 + (color * 255).astype(uint8).  uint8 images = the decoded bytes
+    (eval.py's threaded decode path), float images = a resized image; ``mixed``: every view at its own size.  Also: the download of
+    the record buffer through pinned chunks into a file at an offset, and the overflow report."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from patchmatchnet_amd import fusion, ops
+    V, H, W = 5, 120, 160
+    sizes = [(120, 160), (96, 128), (120, 160), (144, 192), (90, 120)] if mixed else None
+    views = _consistent_scene(V, H, W, sizes, seed=3)
+    ids = sorted(views)
+    for v in ids:  # images as eval.py holds them
+        im = views[v]["image"]
+        views[v]["image"] = np.ascontiguousarray(im, np.float32) if float_images else (im * 255).astype(np.uint8)
+    pairs = [(r, [s for s in ids if s != r]) for r in ids]
+    thr = (1.0, 0.01, 3, 0.5)
+    vsizes = {v: tuple(views[v]["depth"].shape) for v in ids}
+    flat = max(2 * h * w for h, w in vsizes.values())
+    maps = torch.zeros((len(ids), flat), dtype=torch.float32)
+    for i, v in enumerate(ids):
+        h, w = vsizes[v]
+        maps[i, :h * w] = torch.from_numpy(views[v]["depth"]).reshape(-1)
+        maps[i, h * w:2 * h * w] = torch.from_numpy(views[v]["confidence"]).reshape(-1)
+    maps = maps.to(DEV)
+    slot_of = {v: i for i, v in enumerate(ids)}
+    cams = {v: {"intrinsics": views[v]["intrinsics"], "extrinsics": views[v]["extrinsics"]} for v in ids}
+    # host path (rounds 3-4)
+    recs, _, masks = fusion.fuse_views(maps, slot_of, cams, {v: views[v]["image"] for v in ids}, pairs, *thr, sizes=vsizes, as_records=True)
+    want = b"".join(r.tobytes() for r in recs)
+    assert len(want) > 15 * 1000
+    # device path
+    packer = ops.PointPacker(sum(h * w for h, w in vsizes.values()), torch.device(DEV), max_views=8)
+    dev_images = {v: torch.from_numpy(views[v]["image"]).to(DEV) for v in ids}
+    got_masks = {ref: m.cpu().numpy().astype(bool) for ref, m in fusion.fuse_views_packed(maps, slot_of, cams, dev_images, pairs, *thr,
+                                                                                          packer, sizes=vsizes)}
+    counts = packer.counts()
+    assert counts == [len(r) for r in recs]
+    got = packer.records[:15 * sum(counts)].cpu().numpy().tobytes()
+    assert got == want
+    for r in ids:
+        for k in range(3):
+            np.testing.assert_array_equal(got_masks[r][k], masks[r][k])
+    # the body through pinned chunks into a file behind a header (chunk size far below the body: several chunks, two writers)
+    path = str(tmp_path / "body.bin")
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    ring = fusion.PinnedRing(4096 * 15, 3)
+    with ThreadPoolExecutor(2) as pool:
+        os.pwrite(fd, b"HEADER", 0)
+        for f in fusion.download_to_file(packer.records, len(want), fd, 6, ring, pool, torch.cuda.current_stream()):
+            f.result()
+    os.close(fd)
+    assert open(path, "rb").read() == b"HEADER" + want
+    # a second scan re-uses the packer from record 0; a view that does not fit is reported, nothing is written past the buffer
+    packer.reset()
+    small = ops.PointPacker(100, torch.device(DEV), max_views=8)
+    for _ in fusion.fuse_views_packed(maps, slot_of, cams, dev_images, pairs[:1], *thr, small, sizes=vsizes):
+        pass
+    with pytest.raises(Exception, match="too small"):
+        small.counts()
