@@ -827,9 +827,10 @@ class PointPacker:
         self.n = 0
 
     def append(self, final_mask: torch.Tensor, xyz: torch.Tensor, image_hwc: torch.Tensor) -> None:
-        _dev(final_mask, "final_mask")
         _dev(xyz, "xyz")
-        _dev(image_hwc, "image_hwc")
+        for t, name in ((final_mask, "final_mask"), (image_hwc, "image_hwc")):
+            if not isinstance(t, torch.Tensor) or t.device != self.records.device:
+                raise PmnError(f"pack_points: {name} must be a tensor on {self.records.device} (no CPU fallback)")
         H, W = final_mask.shape
         if final_mask.dtype != torch.uint8 or not final_mask.is_contiguous():
             raise PmnError("pack_points: final_mask must be contiguous uint8 [H,W]")
