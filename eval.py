@@ -590,6 +590,7 @@ class ScanFuser:
         self.error = None
         self.stream = torch.cuda.Stream(device)
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse")
+        self.io_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="pmn-ply")  # fused.ply chunks: never queued
         self.state = {}  # buffers that live across scans: the point packer, the pinned rings
         self.thread = threading.Thread(target=self._run, name="pmn-fuser", daemon=True)
         self.thread.start()
@@ -604,7 +605,7 @@ class ScanFuser:
                 continue  # drain: the launch thread will see the first error
             try:
                 with torch.no_grad():
-                    _fuse_scan(self.args, job, self.rank, self.world, self.device, self.stream, self.pool, self.state)
+                    _fuse_scan(self.args, job, self.rank, self.world, self.device, self.stream, self.pool, self.io_pool, self.state)
             except BaseException as e:  # noqa: BLE001 -- handed to the launch thread
                 self.error = e
 
@@ -617,6 +618,7 @@ class ScanFuser:
         self.jobs.put(None)
         self.thread.join()
         self.pool.shutdown(wait=True)
+        self.io_pool.shutdown(wait=True)
         if self.error is not None:
             raise self.error
 
@@ -670,11 +672,12 @@ def filter_depth(args, scan, produced, rank, world, device, fuser=None, scan_ima
     if fuser is not None:
         fuser.submit(job)
     else:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse") as pool:
-            _fuse_scan(args, job, rank, world, device, torch.cuda.current_stream(device), pool, {})
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse") as pool, \
+                concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="pmn-ply") as io_pool:
+            _fuse_scan(args, job, rank, world, device, torch.cuda.current_stream(device), pool, io_pool, {})
 
 
-def _fuse_scan(args, job, rank, world, device, stream, pool, state):
+def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
     """One scan's reference views of this rank: fusion + point packing kernels on ``stream`` (everything stays on the device until
     the scan's PLY body is complete: ONE contiguous record buffer), the three masks of every view through a ring of pinned buffers
     to ``pool`` threads that encode the PNGs, the body in 64 MB chunks through pinned memory to pwrite -- the launch thread of this
@@ -718,7 +721,7 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, state):
             mring = state["mask_ring"] = fusion.PinnedRing(3 * hmax, 8)
         bring = state.get("body_ring")
         if bring is None:
-            bring = state["body_ring"] = fusion.PinnedRing(64 << 20, 4)
+            bring = state["body_ring"] = fusion.PinnedRing(32 << 20, 8)
 
         class Images(dict):  # uploads a host-decoded image the moment its view is fused
             def __missing__(self, ref):
@@ -738,8 +741,10 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, state):
             ev.record(stream)
             pending.append(pool.submit(write_masks, ref, pin, ev, h, w, mring))
             images.pop(ref, None)
+        t_enqueued = time.time()
         counts = packer.counts()  # the only synchronisation with the device: every view's number of points
         total = sum(counts)
+        t_counts = time.time()
         ply = os.path.join(args.output_folder, scan, "fused.ply")
         target = ply if world == 1 else ply + ".part{}.tmp".format(rank)
         header = fusion.ply_header(total) if world == 1 else b""
@@ -747,9 +752,14 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, state):
         try:
             if header:
                 os.pwrite(fd, header, 0)
-            pending += fusion.download_to_file(packer.records, 15 * total, fd, len(header), bring, pool, stream)
-            for f in pending:
+            body = fusion.download_to_file(packer.records, 15 * total, fd, len(header), bring, io_pool, stream)
+            t_chunks = time.time()
+            for f in body:
                 f.result()  # re-raises a writer's exception
+            t_body = time.time()
+            for f in pending:
+                f.result()
+            t_masks = time.time()
         finally:
             os.close(fd)
     for ref, _ in my_pairs:
@@ -782,8 +792,10 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, state):
                 os.remove(p)
     if rank == 0:
         print("saving the final model to", ply)
-    print("fusion stage: {} reference views of {} in {:.3f} s on this rank".format(len(my_pairs), scan or args.input_folder,
-                                                                                 time.time() - t_fuse))
+    print("fusion stage: {} reference views of {} in {:.3f} s on this rank ({} points; launches enqueued {:.3f}, kernels done {:.3f}, "
+          "body chunks queued {:.3f}, body on disk {:.3f}, masks on disk {:.3f} s after the start)".format(
+              len(my_pairs), scan or args.input_folder, time.time() - t_fuse, total, t_enqueued - t_fuse, t_counts - t_fuse,
+              t_chunks - t_fuse, t_body - t_fuse, t_masks - t_fuse))
 
 
 def build_parser():

@@ -146,7 +146,7 @@ def test_packed_records_are_the_host_paths_bytes(mixed, float_images, tmp_path):
     ids = sorted(views)
     for v in ids:  # images as eval.py holds them
         im = views[v]["image"]
-        views[v]["image"] = np.ascontiguousarray(im, np.float32) if float_images else (im * 255).astype(np.uint8)
+        views[v]["image"] = np.ascontiguousarray(im, np.float32) if float_images else np.ascontiguousarray((im * 255).astype(np.uint8))
     pairs = [(r, [s for s in ids if s != r]) for r in ids]
     thr = (1.0, 0.01, 3, 0.5)
     vsizes = {v: tuple(views[v]["depth"].shape) for v in ids}
