@@ -577,8 +577,8 @@ class ScanFuser:
     """--output_type both: the consistency filtering + fusion of a finished scan runs on a WORKER THREAD with its own HIP stream,
     so the launch thread goes straight on to the next scan's inference (the reference fuses after all inference, single-threaded
     numpy, eval.py:193-297; round 4 fused every scan synchronously on the launch thread: 0.75 s of fusion stage behind 0.13 s of
-    inference per 49-view scan).  One scan is fused at a time and at most one waits (back-pressure: a rank holds two scans' maps at
-    most).  The per-scan collective (all-gather of the maps) stays on the launch thread -- collectives from two threads would have to
+    inference per 49-view scan).  --fuse_workers scans are in the stage at once and at most one more waits (back-pressure: a rank holds
+    the maps of a few scans at most).  The per-scan collective (all-gather of the maps) stays on the launch thread -- collectives from two threads would have to
     agree on an order across ranks -- and the worker itself issues none: per-rank PLY parts are published by rename and rank 0
     stitches when all of a scan's parts exist.  An exception in the worker is re-raised on the launch thread at the next submit /
     at close."""
@@ -588,15 +588,18 @@ class ScanFuser:
         self.args, self.rank, self.world, self.device = args, rank, world, device
         self.jobs: "queue.Queue" = queue.Queue(maxsize=1)
         self.error = None
-        self.stream = torch.cuda.Stream(device)
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse")
-        self.io_pool = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="pmn-ply")  # fused.ply chunks: never queued
-        self.state = {}  # buffers that live across scans: the point packer, the pinned rings
-        self.thread = threading.Thread(target=self._run, name="pmn-fuser", daemon=True)
-        self.thread.start()
+        self.io_pool = concurrent.futures.ThreadPoolExecutor(max_workers=8, thread_name_prefix="pmn-ply")  # fused.ply chunks: never queued
+        # --fuse_workers scans are in the fusion stage at once (own stream, point packer and pinned rings each): the stage of one scan
+        # is a chain of short phases (kernels, the count, downloads, encoders draining) and a second scan fills its gaps
+        self.threads = [threading.Thread(target=self._run, name="pmn-fuser-%d" % i, daemon=True)
+                        for i in range(max(getattr(args, "fuse_workers", 2), 1))]
+        for t in self.threads:
+            t.start()
 
     def _run(self) -> None:
         torch.cuda.set_device(self.device)
+        stream, state = torch.cuda.Stream(self.device), {}  # state: buffers that live across scans (point packer, pinned rings)
         while True:
             job = self.jobs.get()
             if job is None:
@@ -605,7 +608,7 @@ class ScanFuser:
                 continue  # drain: the launch thread will see the first error
             try:
                 with torch.no_grad():
-                    _fuse_scan(self.args, job, self.rank, self.world, self.device, self.stream, self.pool, self.io_pool, self.state)
+                    _fuse_scan(self.args, job, self.rank, self.world, self.device, stream, self.pool, self.io_pool, state)
             except BaseException as e:  # noqa: BLE001 -- handed to the launch thread
                 self.error = e
 
@@ -615,8 +618,10 @@ class ScanFuser:
         self.jobs.put(job)
 
     def close(self) -> None:
-        self.jobs.put(None)
-        self.thread.join()
+        for _ in self.threads:
+            self.jobs.put(None)
+        for t in self.threads:
+            t.join()
         self.pool.shutdown(wait=True)
         self.io_pool.shutdown(wait=True)
         if self.error is not None:
@@ -730,21 +735,39 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
                 return self[ref]
 
         images = Images({ref: im for ref, im in job["images"].items() if im is not None})
-        pending = []
+        # 1. every view's kernels, back to back: masks and points stay on the device, nothing waits for the host
+        masks_dev = []
         for ref, m in fusion.fuse_views_packed(job["buf"], job["slot_of"], job["cams"], images, my_pairs, args.geo_pixel_thres,
                                                args.geo_depth_thres, args.geo_mask_thres, args.photo_thres, packer,
                                                sizes=sizes if job["mixed"] else None):
-            h, w = sizes[ref]
-            pin = mring.acquire()  # blocks while eight views' masks are still being encoded
-            pin[:3 * h * w].copy_(m.reshape(-1), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            pending.append(pool.submit(write_masks, ref, pin, ev, h, w, mring))
+            masks_dev.append((ref, m))
             images.pop(ref, None)
         t_enqueued = time.time()
         counts = packer.counts()  # the only synchronisation with the device: every view's number of points
         total = sum(counts)
         t_counts = time.time()
+        # 2. two pipelines side by side: the masks through their pinned ring to the PNG encoders (a feeder thread: the ring blocks
+        #    while eight views are being encoded), the PLY body in chunks through its ring to the pwrite threads
+        pending, feeder_error = [], []
+
+        def feed_masks():
+            try:
+                with torch.cuda.device(device), torch.cuda.stream(stream):
+                    while masks_dev:
+                        ref, m = masks_dev.pop(0)
+                        h, w = sizes[ref]
+                        pin = mring.acquire()
+                        pin[:3 * h * w].copy_(m.reshape(-1), non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        pending.append(pool.submit(write_masks, ref, pin, ev, h, w, mring))
+                        del m
+            except BaseException as e:  # noqa: BLE001 -- re-raised below
+                feeder_error.append(e)
+
+        import threading
+        feeder = threading.Thread(target=feed_masks, name="pmn-masks")
+        feeder.start()
         ply = os.path.join(args.output_folder, scan, "fused.ply")
         target = ply if world == 1 else ply + ".part{}.tmp".format(rank)
         header = fusion.ply_header(total) if world == 1 else b""
@@ -757,10 +780,14 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
             for f in body:
                 f.result()  # re-raises a writer's exception
             t_body = time.time()
+            feeder.join()
+            if feeder_error:
+                raise feeder_error[0]
             for f in pending:
                 f.result()
             t_masks = time.time()
         finally:
+            feeder.join()
             os.close(fd)
     for ref, _ in my_pairs:
         photo, geo, final = fractions[ref]
@@ -842,7 +869,8 @@ def build_parser():
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
                         "(-1 = one RNG stream per process, like the reference)")
     p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
-    p.add_argument("--fuse_threads", type=int, default=8,
+    p.add_argument("--fuse_workers", type=int, default=2, help="--output_type both with --fuse_async 1: scans in the fusion stage at once")
+    p.add_argument("--fuse_threads", type=int, default=-1,
                    help="threads of the fusion stage: mask PNG encoding, reference images the run did not decode itself, fused.ply chunks")
     p.add_argument("--fuse_async", type=int, default=1,
                    help="--output_type both: 1 = a finished scan is filtered + fused on a worker thread with its own HIP stream while "
@@ -888,6 +916,8 @@ def main(argv=None):
     share = max((os.cpu_count() or 4) // max(world, 1), 1)  # this rank's share of the host's hardware threads
     if args.num_workers < 0:  # DataLoader worker PROCESSES (plain path): each forks a process with a GPU context -- keep them few
         args.num_workers = max(min(share - 2, 8), 2)
+    if args.fuse_threads < 0:  # PNG encoders of the fusion stage (3 masks per reference view, ~7 ms each at 1600x1200)
+        args.fuse_threads = max(min(share // 2, 16), 2)
     if args.decode_threads < 0:  # decode THREADS of the encode-once path
         args.decode_threads = max(min(share - 2, 8), 2)  # measured: 8 threads 256-262 depth-maps/s, 32: 242, 64: 195 (GIL)
     if _DISCARD_MAPS:  # a measurement aid (scripts/eval_bench.py), never silent: the run reports every iteration and writes no map
