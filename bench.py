@@ -472,12 +472,12 @@ def main():
             region["run"] = run
             return run(args.steps)
 
-        def timed_in_flight():
+        def timed_in_flight(copy_inputs=args.copy_inputs, publish=True):
             """Returns the elapsed time, or None when some rank could not capture its graphs (decided collectively before the
             timed region, so that every rank then takes the same path)."""
             from patchmatchnet_amd.graph import GraphedForward
             streams = [torch.cuda.Stream(device) for _ in range(S)]
-            slots = [GraphedForward(model, inputs_in_place=not args.copy_inputs) for _ in range(S)]
+            slots = [GraphedForward(model, inputs_in_place=not copy_inputs) for _ in range(S)]
 
             def replay(i):
                 k, s = i % S, samples[i % len(samples)]
@@ -495,7 +495,10 @@ def main():
                 err = str(e).split("\n")[0][:120] or "RuntimeError"
             if reduce_scalar(0.0 if err else 1.0, dist.ReduceOp.MIN) < 1.0:
                 return None, err or "capture failed on another rank"
+            keep = extra_warmup[0]
             settle(replay)
+            if not publish:
+                extra_warmup[0] = keep  # (the line reports the untimed steps before `value`'s region)
 
             def run(steps):
                 barrier()
@@ -508,7 +511,8 @@ def main():
                 close_region(outs)
                 return time.perf_counter() - t0
 
-            region["run"] = run
+            if publish:
+                region["run"] = run
             return run(args.steps), ""
 
         if args.eager:
@@ -528,6 +532,14 @@ def main():
             n_steady = int(reduce_scalar(float(n_steady), dist.ReduceOp.MAX))  # every rank runs the same count
             steady = (n_steady, reduce_scalar(region["run"](n_steady), dist.ReduceOp.MAX))
 
+
+        # the other input mode beside `value` (rounds 2-4's `value` had all six images copied into the slot's static buffers inside the
+        # timed region; eval.py's pipeline, which recycles its upload buffers, runs that mode): the same K steps, same box, same process
+        other_mode = None
+        if not args.eager and launch_note is None:
+            alt, _ = timed_in_flight(copy_inputs=not args.copy_inputs, publish=False)
+            if alt is not None:
+                other_mode = reduce_scalar(alt, dist.ReduceOp.MAX)
 
     # per-rank spread beside the max-reduced figure, and proof that the collectives saw every rank (a line printed by a job whose
     # ranks never met would otherwise look like an N-GPU result)
@@ -609,6 +621,10 @@ def main():
                        f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU; images "
                        + ("copied into the slot's static buffers" if args.copy_inputs else
                           "read in place through a device table of addresses (pmn_stem_f16s_views)"))},
+            "value_other_input_mode": None if other_mode is None else {
+                "mode": "images read in place through a device table of addresses" if args.copy_inputs else
+                        "all six images copied into the slot's static buffers inside the timed region (rounds 2-4's `value`, eval.py's mode)",
+                "value": round(world * args.steps / other_mode, 4), "ms_per_step": round(other_mode / args.steps * 1e3, 4)},
             "steady_state": None if steady is None else {
                 "steps": steady[0], "seconds": round(steady[1], 3), "value": round(world * steady[0] / steady[1], 2),
                 "note": "the timed region's loop repeated for ~%.0f s in the same mode (not the contract's K steps)" % args.steady_seconds},

@@ -57,7 +57,24 @@ class GraphedForward:
     def _signature(cls, images: Sequence[torch.Tensor], intrinsics: torch.Tensor, features) -> Tuple:
         feat = None if features is None else tuple(tuple((s, tuple(t.shape)) for s, t in sorted(f.items())) for f in features)
         return (tuple(tuple(i.shape) for i in images), cls._alias_pattern(images), tuple(intrinsics.shape), feat,
-                features is not None and cls._table_ok(features))
+                features is not None and cls._table_ok_cached(features))
+
+    _TABLE_OK: Dict[Tuple, bool] = {}
+
+    @classmethod
+    def _table_ok_cached(cls, features) -> bool:
+        """``_table_ok`` once per (shape, stride) pattern of the injected maps instead of ~18 permute / is_contiguous checks per sample on
+        the launch thread (the answer depends on layout only, not on which scan's pyramids these are)."""
+        try:
+            key = tuple((s, tuple(t.shape), tuple(t.stride()), t.dtype, t.is_cuda) for f in features for s, t in sorted(f.items()))
+        except (AttributeError, TypeError):
+            return cls._table_ok(features)
+        hit = cls._TABLE_OK.get(key)
+        if hit is None:
+            if len(cls._TABLE_OK) > 64:
+                cls._TABLE_OK.clear()
+            hit = cls._TABLE_OK[key] = cls._table_ok(features)
+        return hit
 
     def _images_in_place(self, features) -> bool:
         """The replayed FeatureNet can read the images through a table: asked for, FeatureNet is part of the graph, and its stem is the
@@ -188,16 +205,22 @@ class GraphedForward:
     def _fill(cls, static, images, intrinsics, extrinsics, depth_min, depth_max, features) -> None:
         if "image_table" in static:
             from . import ops
-            bufs, addrs = static["image_bufs"], []
+            bufs, addrs, held = static["image_bufs"], [], []
             for i, im in enumerate(images):
-                if i == 0 or not ops.SourceTable.image_in_place(im):
+                if i == 0 or im.device != static["intrinsics"].device or not ops.SourceTable.image_in_place(im):
                     if bufs[i] is None:
                         bufs[i] = torch.empty(tuple(images[0].shape), dtype=torch.float32, device=static["intrinsics"].device)
                     if bufs[i].data_ptr() != im.data_ptr():
                         bufs[i].copy_(im, non_blocking=True)
                     addrs.append(bufs[i].data_ptr())
                 else:
+                    # read WHERE IT IS by the replay about to be enqueued on the current stream: tell the caching allocator (a caller
+                    # that drops the image right after this call must not get its block handed to another stream before the stem has
+                    # read it), and keep the tensor until the slot's next sample replaces it
+                    im.record_stream(torch.cuda.current_stream(im.device))
+                    held.append(im)
                     addrs.append(im.data_ptr())
+            static["held_images"] = held
             cls._stage_addresses(static, addrs)
         else:
             done = set()

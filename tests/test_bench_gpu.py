@@ -48,6 +48,9 @@ def test_bench_line_default_and_eager():
         line = _line(p.stdout)
         _check(line, 1)
         assert line["config"]["in_flight"] == (1 if extra else 3)
+        # both input modes of the graph replay are on the line (in place = `value`; copied into the slot = rounds 2-4's `value`)
+        other = line["value_other_input_mode"]
+        assert (other is None) == bool(extra) and (extra or (other["value"] > 0 and "copied" in other["mode"]))
         assert ("graph" in line["config"]["launch"]) == (not extra), line["config"]["launch"]
 
 

@@ -138,8 +138,9 @@ def test_kernels_against_golden(case, stage):
             ref_nhwc, src_nhwc, rel, hyp, vw_in, 0, pm.evaluation.similarity_net.packed_device(),
             pm.evaluation.pixel_wise_net.packed_device() if vw_in is None else None, cfg.G, want_similarity=True,
             want_argmax=vw_in is None)
-        # (tap positions come from a v_rcp-based projection: ~1e-4 px from the reference's, see gather_corr.hip)
-        assert GU.abs_err(n(sim), g[key + "similarity"]) < 1e-4
+        # (since round 4 the tap positions come out of the reference's own IEEE chain, pmn_pose_position: what is left is the fp32
+        #  summation order of the blend / group mean -- full-size maxima on random features: <= 2.4e-5, profiles/r0*_parity_report.jsonl)
+        assert GU.abs_err(n(sim), g[key + "similarity"]) < 3e-5
         assert GU.abs_err(n(vw_out), g[key + "view_weights"]) < 1e-5
         if vw_in is None:
             # "bit-exact on view_weights indices": arg-max over D of the PixelwiseNet response == oracle's
