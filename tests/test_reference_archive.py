@@ -63,7 +63,10 @@ def test_input_type_module_builds_the_hip_module_from_the_archive():
     build patchmatchnet_amd.PatchmatchNet -- same names, same values as the params checkpoint gives; a variant archive (other
     sample / neighbour counts) round-trips its own lists."""
     path, make_ref = _archive()
-    import eval as ev
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmn_eval_cli", os.path.join(ROOT, "eval.py"))  # (by path: other tests put the
+    ev = importlib.util.module_from_spec(spec)                                                     #  reference checkout on sys.path)
+    spec.loader.exec_module(ev)
     import patchmatchnet_amd as P
     args = ev.build_parser().parse_args(["--input_folder", "x", "--output_folder", "y", "--checkpoint_path", path,
                                          "--input_type", "module"])
