@@ -244,6 +244,8 @@ class DevicePrefetcher:
         return t
 
     def _stage(self, sample):
+        if "depth_min" in self.keys:
+            _check_depth_range(sample)  # host numbers here, device tensors afterwards
         out = dict(sample)
         with torch.cuda.stream(self.stream):
             for k in self.keys:
@@ -310,6 +312,19 @@ class CameraUploader:
             out.append(dev[off:off + p_.numel()].view(p_.shape))
             off += p_.numel()
         return out
+
+
+def _check_depth_range(sample) -> None:
+    """The kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite -- checked while the values are still host
+    numbers (before upload).  A degenerate range makes the reference divide by zero (models/patchmatch.py:656-657: inf / NaN maps);
+    the kernels' division sequence is IEEE for normal operands only, so such a sample is refused instead of producing NaN maps."""
+    lo, hi = (np.atleast_1d(np.asarray(sample[k], np.float64)) for k in ("depth_min", "depth_max"))
+    bad = ~(np.isfinite(lo) & np.isfinite(hi) & (lo > 0.0) & (lo < hi))
+    if bad.any():
+        i = int(np.argmax(bad))
+        name = sample["filename"][i] if isinstance(sample["filename"], (list, tuple)) else sample["filename"]
+        raise P.PmnError("{}: depth range [{}, {}] is not 0 < depth_min < depth_max (finite): line 11 of the reference view's camera "
+                         "file must read 'depth_min depth_max'".format(name, lo[i], hi[i]))
 
 
 def _seed_sample(args, dataset, sample) -> None:
@@ -435,6 +450,7 @@ def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
             (0.3 ms of the launch thread per sample at 300 samples/s): the camera tensors with a batch dimension, the rest as lists."""
             for i in indices:
                 s = dataset[i]
+                _check_depth_range(s)
                 yield {"intrinsics": torch.from_numpy(s["intrinsics"])[None], "extrinsics": torch.from_numpy(s["extrinsics"])[None],
                        "depth_min": torch.tensor([s["depth_min"]], dtype=torch.float64),
                        "depth_max": torch.tensor([s["depth_max"]], dtype=torch.float64), "ref_view": torch.tensor([s["ref_view"]]),
@@ -519,6 +535,7 @@ def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
         loader = DataLoader(subset, batch_size=1, shuffle=False, num_workers=0, drop_last=False)  # camera text files only
         for sample in loader:
             start = time.time()
+            _check_depth_range(sample)
             ids = [int(v) for v in sample["view_ids"][0]]
             ref_img = images[ids[0]]
             _seed_sample(args, dataset, sample)

@@ -77,7 +77,7 @@ int pmn_feature_weight(const float *ref_nhwc, const float *eval_offsets, const i
  * depth_min/depth_max: device float[B].  PRECONDITION of every entry point that takes them or depth hypotheses: finite,
  * 0 < depth_min < depth_max, previous depths finite and > 0 -- the kernels' divisions are hipcc's IEEE fma sequence without its
  * v_div_scale / v_div_fixup shell (csrc/pmn_common.hpp), bit-identical for normal operands; a zero or infinite divisor (a degenerate
- * range) yields NaN where the reference's division yields inf.  The host side refuses such camera files (patchmatchnet_amd/mvs.py).
+ * range) yields NaN where the reference's division yields inf.  eval.py refuses such samples before upload (its _check_depth_range).
  * Outputs: depth_sample [B,D,h,w] and its normalised inverse depth
  * xnorm = (1/d - 1/dmax)/(1/dmin - 1/dmax) (reference :655-657), stored HYPOTHESIS-LAST [B,h,w,D] for
  * pmn_aggregate_regress (its only consumer: one bilinear corner of a neighbour = D contiguous floats). */

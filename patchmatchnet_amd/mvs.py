@@ -116,11 +116,6 @@ class MVSDataset(Dataset):
             extrinsics.append(E)
             if i == 0:
                 depth_min, depth_max = depth_params[0], depth_params[1]
-                # the kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite -- checked here, where the values are
-                # still host numbers.  A degenerate range makes the reference divide by zero (models/patchmatch.py:656-657: inf / NaN
-                # maps); the kernels' division sequence is IEEE for normal operands only, so such a camera file is refused instead.
-                if not (np.isfinite(depth_min) and np.isfinite(depth_max) and 0.0 < depth_min < depth_max):
-                    raise ValueError("{}: depth range [{}, {}] is not 0 < depth_min < depth_max (finite)".format(cam_path, depth_min, depth_max))
         return {"images": images, "intrinsics": np.stack(intrinsics), "extrinsics": np.stack(extrinsics),
                 "depth_min": depth_min, "depth_max": depth_max, "ref_view": view_ids[0],
                 "view_ids": np.asarray(view_ids, np.int64), "scan": scan, "light": light,

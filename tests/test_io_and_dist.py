@@ -147,27 +147,26 @@ def test_camera_only_samples_and_view_dataset(tmp_path):
 
 
 def test_degenerate_depth_range_is_refused(tmp_path):
-    """The kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite.  A camera file with a degenerate range
-    (the reference then divides by zero, models/patchmatch.py:656-657) is refused by the dataset, where the values are host numbers."""
+    """The kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite.  eval.py refuses a sample with a degenerate
+    range (the reference then divides by zero, models/patchmatch.py:656-657) while the values are host numbers; the dataset itself
+    stays the reference's (it hands out whatever line 11 of the camera file holds, tests/test_reference_io.py)."""
+    import importlib.util
     import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmn_eval_cli", os.path.join(root, "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
     synth.write_scan(str(tmp_path), "scan1", n_views=3, H=64, W=96, n_src=2)
     with open(tmp_path / "list.txt", "w") as f:
         f.write("scan1\n")
-    cam = tmp_path / "scan1" / "cams" / "00000001_cam.txt"
-    lines = cam.read_text().split("\n")
-    good = lines[11].split()
     ds = MVSDataset(str(tmp_path), num_views=2, scan_list=str(tmp_path / "list.txt"))
-    assert ds[1]["depth_min"] > 0
-    for bad in ([good[0], "0.0", good[0]] + good[3:], ["0.0"] + good[1:], ["inf"] + good[1:]):
-        broken = list(lines)
-        broken[11] = " ".join(bad)
-        cam.write_text("\n".join(broken))
-        fresh = MVSDataset(str(tmp_path), num_views=2, scan_list=str(tmp_path / "list.txt"))
-        # (line 11 = depth_min interval num max in the MVSNet format; the dataset reads [0] and [1] as min / max like the reference)
-        if not (0.0 < float(bad[0]) < float(bad[1]) and np.isfinite(float(bad[0]))):
-            with pytest.raises(ValueError, match="depth range"):
-                fresh[1]
-        fresh[0]  # the other reference views are unaffected
+    good = ds[1]
+    ev._check_depth_range(good)
+    ev._check_depth_range({"depth_min": torch.tensor([good["depth_min"]], dtype=torch.float64),  # the collated form
+                           "depth_max": torch.tensor([good["depth_max"]], dtype=torch.float64), "filename": [good["filename"]]})
+    for lo, hi in ((425.0, 425.0), (425.0, 2.5), (0.0, 935.0), (-1.0, 935.0), (425.0, float("inf")), (float("nan"), 935.0)):
+        with pytest.raises(Exception, match="depth range"):
+            ev._check_depth_range(dict(good, depth_min=np.float32(lo), depth_max=np.float32(hi)))
 
 
 def _gather_worker(rank, world, port, H, W, ids, q):
