@@ -359,13 +359,17 @@ extern "C" int pmn_offset_heads_f16s(const float* in, const void* weights, const
 // output pointer per lane), 44 -> 38 us per view with bit-identical results.  Tried and measured equal: a 14 x 14 tile (halo patch =
 // one pass of 256 threads), alternating the second conv0 pass between wave pairs, 8 instead of 6 workgroups per CU.
 // =================================================================================================================================
-template <bool VEC4>
+#ifndef PMN_STEM_TH
+#define PMN_STEM_TH 32  // output rows per workgroup tile (16 x TH pixels): 32 amortises the per-tile skeleton (round 5); 16 = rounds 3-4
+#endif
+template <bool VEC4, int TH>
 __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restrict__ img, const float* __restrict__ w0,
                                                           const float* __restrict__ s0, const f16x8* __restrict__ w1A,
                                                           const float* __restrict__ s1, float* __restrict__ out, const int N,
                                                           const int H, const int W, const float* const* __restrict__ img_tab,
                                                           const int BV) {
-    constexpr int TS = 16, IW = TS + 4, XS = 24, MW = TS + 2, MRP = 18, MROWS = 18, NTHR = 256;
+    constexpr int TS = 16, IW = TH + 4, XS = 24, MW = TS + 2, MRP = 18, MROWS = TH + 2, NTHR = 256;  // IW / MROWS: patch / halo ROWS
+    static_assert(TH % 16 == 0, "a wave owns TH / 4 rows, four at a time");
     __shared__ float4 xin4[3 * IW * (XS / 4)];
     __shared__ float4 mid4[2 * MROWS * MRP];  // two planes of 18 x 18 pixel slots x 8 halves (16 B)
     float* xin = reinterpret_cast<float*>(xin4);
@@ -375,10 +379,10 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
     const cfloat* cw0 = (const cfloat*)w0;  // [3][3][3][8]
     const cfloat* cs0 = (const cfloat*)s0;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kb = lane >> 4;
-    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+    const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TH - 1) / TH;
     const int bt = pmn_xcd_tile(blockIdx.x, N * tiles_x * tiles_y);
     const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
-    const int oy0 = (tr / tiles_x) * TS, ox0 = (tr % tiles_x) * TS;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * TS;
     // image n of the launch: a slice of one [N,3,H,W] tensor, or -- pmn_stem_f16s_views -- batch element n % BV of the view n / BV
     // whose [BV,3,H,W] tensor sits wherever the device table says (wave-uniform: one scalar load)
     if (img_tab) img = img_tab[n / BV] + (ptrdiff_t)((n % BV) - n) * 3 * H * W;  // (the indexing below adds n * 3 * H * W)
@@ -392,10 +396,11 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
     }
     // (1) input patch, every load of the thread in flight before the first LDS write.  Row R of 60 = (channel, patch row).
     if constexpr (VEC4) {
-        float4 v[2];
+        constexpr int NU = (3 * IW + 31) / 32;  // passes of 32 rows
+        float4 v[NU];
         const int j = tid & 7, gx = ox0 - 4 + 4 * j;  // float4 j of the row (6 used)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int R = (tid >> 3) + 32 * u;
             const int c = (R >= IW) + (R >= 2 * IW), r = R - IW * c, gy = oy0 - 2 + r;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -403,15 +408,16 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
                 v[u] = *reinterpret_cast<const float4*>(img + (((size_t)n * 3 + c) * H + gy) * W + gx);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int R = (tid >> 3) + 32 * u;
             if (j < 6 && R < 3 * IW) xin4[R * (XS / 4) + j] = v[u];
         }
     } else {  // any width: one float per thread, 8 rows of 32 columns (24 used) per pass
-        float v[8];
+        constexpr int NU = (3 * IW + 7) / 8;  // passes of 8 rows
+        float v[NU];
         const int q = tid & 31, gx = ox0 - 4 + q;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int R = (tid >> 5) + 8 * u;
             const int c = (R >= IW) + (R >= 2 * IW), r = R - IW * c, gy = oy0 - 2 + r;
             v[u] = 0.0f;
@@ -419,14 +425,14 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
                 v[u] = img[(((size_t)n * 3 + c) * H + gy) * W + gx];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int R = (tid >> 5) + 8 * u;
             if (q < XS && R < 3 * IW) xin[R * XS + q] = v[u];
         }
     }
     __syncthreads();
     // (2) conv0 + BN + ReLU on the halo patch (fp32, same order of operations as stem_kernel) -> hi / lo planes
-    for (int m = tid; m < MW * MW; m += NTHR) {
+    for (int m = tid; m < MW * MROWS; m += NTHR) {
         const int r = m / MW, q = m - r * MW;
         const int gy = oy0 - 1 + r, gx = ox0 - 1 + q;
         f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -463,7 +469,10 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         *reinterpret_cast<f16x8*>(midl + (r * MRP + q) * 8) = lo;
     }
     __syncthreads();
-    // (3) conv1: D[cout][pixel] += W[cout][k] * mid[k][pixel]
+    // (3) conv1: D[cout][pixel] += W[cout][k] * mid[k][pixel]; a wave owns TH / 4 output rows, four at a time
+#pragma unroll 1
+    for (int rg = 0; rg < TH / 16; ++rg) {
+    const int wrow = wave * (TH / 4) + 4 * rg;
     f32x4_t accM[4], accL[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         q = q < 8 ? q : 8;  // padding blocks 9..11 (zero weights) read tap 8
         const int dy = q / 3, dx = q - dy * 3;
         // (rows up to 4*3 + 3 + 2 = 17 and columns up to 15 + 2 = 17: inside the 18 x 18 slots)
-        const _Float16* pb = midh + ((wave * 4 + dy) * MRP + li + dx) * 8;
+        const _Float16* pb = midh + ((wrow + dy) * MRP + li + dx) * 8;
         f16x8 bh[4], blo[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
         for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][1], bh[t], accL[t], 0, 0, 0);
     }
     // D rows 4 kb + r = output channels: lanes with kb < 2 hold channels [4 kb, 4 kb + 4) of pixel (ox0 + li, oy0 + 4 wave + t)
-    const int ox = ox0 + li, oyw = oy0 + wave * 4;
+    const int ox = ox0 + li, oyw = oy0 + wrow;
     if (kb < 2 && ox < W) {
         const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(s1 + 4 * kb);
         float* po = out + (((size_t)n * H + oyw) * W + ox) * 8 + 4 * kb;
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
             }
         }
     }
+    }
 }
 
 // img [N,3,H,W] planar; w0 [3][3][3][8] / s0 [8] (pack_conv layout, fp32); w1a DEVICE fp16 [3][2][64][8] (params.pack_stem_conv1_f16s:
@@ -512,14 +522,14 @@ __global__ __launch_bounds__(256, 4) void stem_f16s_kernel(const float* __restri
 extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0, const void* w1a, const float* s1, float* out,
                              int N, int H, int W, void* stream) {
     if (!img || !w0 || !s0 || !w1a || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
-    constexpr int TS = 16;
-    const int blocks = N * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+    constexpr int TS = 16, TH = PMN_STEM_TH;
+    const int blocks = N * ((W + TS - 1) / TS) * ((H + TH - 1) / TH);
     // aligned float4 staging needs 16-byte aligned image rows: W % 4 == 0 and a 16-byte aligned base
     if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0)
-        hipLaunchKernelGGL(stem_f16s_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+        hipLaunchKernelGGL((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
     else
-        hipLaunchKernelGGL(stem_f16s_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+        hipLaunchKernelGGL((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -533,14 +543,14 @@ extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0,
 extern "C" int pmn_stem_f16s_views(const float* const* img_table, int views, const float* w0, const float* s0, const void* w1a,
                                    const float* s1, float* out, int B, int H, int W, void* stream) {
     if (!img_table || !w0 || !s0 || !w1a || !s1 || !out || views < 1 || B < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
-    constexpr int TS = 16;
+    constexpr int TS = 16, TH = PMN_STEM_TH;
     const int N = views * B;
-    const int blocks = N * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+    const int blocks = N * ((W + TS - 1) / TS) * ((H + TH - 1) / TH);
     if (W % 4 == 0)
-        hipLaunchKernelGGL(stem_f16s_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+        hipLaunchKernelGGL((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
     else
-        hipLaunchKernelGGL(stem_f16s_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+        hipLaunchKernelGGL((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

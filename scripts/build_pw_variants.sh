@@ -38,3 +38,8 @@ wait
   rest=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v 'gather_corr.o\|aggregate.o\|hypotheses.o\|misc.o')
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_atendiv.so $objs $rest
   echo "built build/pw/libpmn_hip_atendiv.so" )
+# stem A/B (scripts/stem_ab.py): the tree's library with the stem's workgroup tile 16 rows high (rounds 3-4) instead of 32
+( /opt/rocm/bin/hipcc $FLAGS -DPMN_STEM_TH=16 -c $CS/conv_f16s.hip -o build/pw/conv_f16s_stem16.o
+  rest=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v 'conv_f16s.o')
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_stem16.so build/pw/conv_f16s_stem16.o $rest
+  echo "built build/pw/libpmn_hip_stem16.so" )

@@ -23,10 +23,15 @@ config = sys.argv[3] if len(sys.argv) > 3 else "1600x1200_N5"  # WxH_N<source vi
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(src, "p*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"gather_corr_kernel<(\d+), (\d+), (\d+), (\d+)", r["Kernel_Name"])
-        if not m or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
-        C, G, mode, DT = (int(x) for x in m.groups())
+        if "pixelwise_wave_kernel<" in r["Kernel_Name"]:  # round 5: the PixelwiseNet launch of stage 3 (C = 64, G = 8, D <= 64)
+            C, G, mode, DT = 64, 8, 1, 64
+        else:
+            m = re.search(r"gather_corr_kernel<(\d+), (\d+), (\d+), (\d+)", r["Kernel_Name"])
+            if not m:
+                continue
+            C, G, mode, DT = (int(x) for x in m.groups())
         if mode == 2:
             continue
         vals[f"C{C}_D{DT}_{'pixelwise' if mode == 1 else 'vw'}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
