@@ -20,6 +20,6 @@ RUNS=${RUNS:-1 2 3 4 5 6}
 for i in $RUNS; do
   extra=""; [ $i -ge 5 ] && extra="$EXTRA_ENV"
   rm -rf $B/out
-  env $extra python eval.py --input_folder $B/data --output_folder $B/out --checkpoint_path tests/golden/params_000007.npz --scan_list $B/data/list.txt --num_views 5 --file_format .pfm --output_type $OUTPUT_TYPE --geo_mask_thres 3 $EVAL_EXTRA 2>&1 | grep -E "depth stage|both stages|fusion of the last|fusion stage.*scan(7|8) |bound to|Error|error" | sed "s/^/run $i $extra: /"
+  env $extra python eval.py --input_folder $B/data --output_folder $B/out --checkpoint_path tests/golden/params_000007.npz --scan_list $B/data/list.txt --num_views 5 --file_format .pfm --output_type $OUTPUT_TYPE --geo_mask_thres 3 $EVAL_EXTRA 2>&1 | grep -a -E "depth stage|both stages|fusion of the last|fusion stage.*scan(7|8) |bound to|Error|error" | sed "s/^/run $i $extra: /"
 done | tee gpurun_out/eval_procs_$OUTPUT_TYPE.log
 rm -rf $B
