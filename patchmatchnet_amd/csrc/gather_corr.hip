@@ -637,6 +637,9 @@ __device__ __forceinline__ unsigned long long dpp_max_u64(const unsigned long lo
 #ifndef PMN_PW_WAVES
 #define PMN_PW_WAVES 4  // waves per SIMD the launch is compiled for
 #endif
+#ifndef PMN_PW_INTERLEAVE
+#define PMN_PW_INTERLEAVE 1  // PW = 2: lane group k of a pixel walks hypotheses k, k + 2, ... (1: 2 % faster at configs[1]) or the block [k*DL, (k+1)*DL) (0)
+#endif
 
 template <int PW, bool EXACT>
 __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel(const GatherArgs a) {
@@ -650,6 +653,11 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
     constexpr int PS = G * GS;             // LDS floats per pixel
     constexpr int WPB = PMN_BLOCK / 64;    // waves per workgroup
     constexpr int NPIX = WPB * PW;         // pixels per workgroup
+    // LDS position of a hypothesis inside its (pixel, group) row: lane group k's il-th item sits at k*DL + il.  Which hypothesis that
+    // is: the block form (d = position) or, interleaved, d = k + LGP*il -- the lane groups of a pixel then gather NEIGHBOURING
+    // hypotheses in the same instruction (their taps share cache lines) instead of two segments half an epipolar line apart.
+    constexpr bool IL = PMN_PW_INTERLEAVE != 0 && LGP > 1;
+    auto hyp_of = [](int kk, int il) { return IL ? kk + LGP * il : kk * DL + il; };
     static_assert(PW == 4 || PW == 2, "pixels per wave");
     static_assert(NIT % 2 == 0, "PixelwiseNet runs on pairs of items");
 
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
     bool rok[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) {
-        const int d = k * DL + lc + j * LPI;
+        const int d = hyp_of(k, lc + j * LPI);
         rok[j] = okB && (EXACT || d < D);
         rdep[j] = rok[j] ? a.depth[((size_t)b * D + d) * hw + pB] : 1.0f;
     }
@@ -782,7 +790,7 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
             const float r[2] = {rq[0].x, rq[0].y};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int d = d0 + 2 * c + i;
+                const int d = hyp_of((d0 + 2 * c + i) / DL, (d0 + 2 * c + i) % DL);
                 if (EXACT || d < D) {
                     const unsigned long long key = ((unsigned long long)__float_as_uint(pmn_sigmoid(r[i])) << 32) |
                                                    (unsigned long long)(0xFFFFFFFFu - (unsigned)d);
@@ -828,7 +836,13 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
         for (int g = 0; g < G; ++g) ssum[j][g] = ssum[j][g] / wsum;
     mlp_items<G, NIT, 2>(wlds_a, ssum, o);
     float* orow = a.out + ((size_t)b * hw + pA) * D + d0;  // cost is hypothesis-last [B,h,w,D]
-    if constexpr (EXACT) {
+    if constexpr (IL) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int d = hyp_of((d0 + j) / DL, (d0 + j) % DL);
+            if (EXACT || d < D) a.out[((size_t)b * hw + pA) * D + d] = o[j];
+        }
+    } else if constexpr (EXACT) {
         if constexpr (NIT == 4) *reinterpret_cast<float4*>(orow) = make_float4(o[0], o[1], o[2], o[3]);
         else *reinterpret_cast<float2*>(orow) = make_float2(o[0], o[1]);
     } else {
@@ -838,11 +852,13 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
     }
     if (a.sim_out) {
 #pragma unroll
-        for (int j = 0; j < NIT; ++j)
-            if (d0 + j < D) {
+        for (int j = 0; j < NIT; ++j) {
+            const int d = hyp_of((d0 + j) / DL, (d0 + j) % DL);
+            if (d < D) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d0 + j) * hw + pA] = ssum[j][g];
+                for (int g = 0; g < G; ++g) a.sim_out[(((size_t)b * G + g) * D + d) * hw + pA] = ssum[j][g];
             }
+        }
     }
 }
 

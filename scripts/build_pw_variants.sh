@@ -43,3 +43,5 @@ wait
   rest=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v 'conv_f16s.o')
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/pw/libpmn_hip_stem16.so build/pw/conv_f16s_stem16.o $rest
   echo "built build/pw/libpmn_hip_stem16.so" )
+# PixelwiseNet launch, two lane groups per pixel walking interleaved hypotheses (-DPMN_PW_INTERLEAVE=1) instead of two blocks
+build g2il $CS/gather_corr.hip -DPMN_PW=2 -DPMN_PW_WAVES=4 -DPMN_PW_INTERLEAVE=1
