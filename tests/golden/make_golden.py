@@ -50,11 +50,11 @@ def t2n(t):
     return t.detach().cpu().numpy()
 
 
-def dump_cascade(path, model, n_views, H, W, B=1, seed=1234):
+def dump_cascade(path, model, n_views, H, W, B=1, seed=1234, cameras=None):
     imgs = refutil.synthetic_images(n_views, H, W)
     if B > 1:
         imgs = [torch.cat([im, torch.flip(im, dims=[3])] + [im] * (B - 2), 0)[:B].contiguous() for im in imgs]
-    intr, extr = refutil.synthetic_cameras(n_views, H, W)
+    intr, extr = refutil.synthetic_cameras(n_views, H, W) if cameras is None else cameras
     intr = np.repeat(intr, B, 0)
     extr = np.repeat(extr, B, 0)
     dmin = np.array([425.0, 400.0][:B], np.float32)
@@ -240,6 +240,13 @@ def dump_ops(path):
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+def dump_rig(path, model):
+    """Round 5: a rig without the y-axis symmetry of every other fixture (tests/synth.general_cameras: roll, pitch, off-orbit
+    translations, fx != fy, per-view principal points) -- every entry of the relative projections is exercised."""
+    import synth
+    dump_cascade(path, model, 4, 96, 128, seed=777, cameras=synth.general_cameras(4, 96, 128))
+
+
 def main():
     assert refutil.have_reference(), "needs /root/reference"
     torch.manual_seed(0)
@@ -256,6 +263,9 @@ def main():
         return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "dilations":
         dump_dilations(os.path.join(HERE, "cascade_dilations.npz"))
+        return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "rig":
+        dump_rig(os.path.join(HERE, "cascade_general_rig.npz"), model)
         return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "resized":
         dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
@@ -294,6 +304,7 @@ def main():
     dump_resized(os.path.join(HERE, "cascade_resized_100x130.npz"), model)
     dump_counts(os.path.join(HERE, "cascade_odd_counts.npz"))
     dump_dilations(os.path.join(HERE, "cascade_dilations.npz"))
+    dump_rig(os.path.join(HERE, "cascade_general_rig.npz"), model)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,11 @@ CASES = {
                     propagate_neighbors=[0, 8, 16], evaluate_neighbors=[9, 9, 9])),
     # ... and under non-default propagation ranges: other head dilations (fp32 head convolution instead of the fp16-split kernel) and
     # other fixed neighbour tables
+    # a rig without the y-axis symmetry of the other fixtures (synth.general_cameras): roll, pitch, off-orbit translations, fx != fy
+    "rig": ("cascade_general_rig.npz", "params_000007.npz",
+            dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[6, 4, 2],
+                 patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[8, 8, 16],
+                 propagate_neighbors=[0, 8, 16], evaluate_neighbors=[9, 9, 9])),
     "dilations": ("cascade_dilations.npz", "params_000007.npz",
                   dict(patchmatch_interval_scale=[0.005, 0.0125, 0.025], propagation_range=[5, 3, 2],
                        patchmatch_iteration=[1, 2, 2], patchmatch_num_sample=[8, 8, 16],

@@ -25,6 +25,39 @@ def synthetic_cameras(n_views: int, H: int, W: int):
     return intr[None], np.stack(extr).astype(np.float32)[None]
 
 
+def general_cameras(n_views: int, H: int, W: int):
+    """A rig WITHOUT the symmetries of ``synthetic_cameras`` (rotations about the y axis only: there the relative projections have
+    exact zeros where a general pose has none -- the y coefficients of x and z -- and every epipolar line is horizontal): each source
+    camera is rotated about its own tilted axis (so it also rolls and pitches), sits off the reference's baseline in x, y AND z, and
+    has its own focal lengths (fx != fy) and principal point.  Same contract: (intrinsics [1,N,3,3], extrinsics [1,N,4,4]); the
+    cameras look at the point (0,0,650)."""
+    intr, extr = [], []
+    P = np.array([0.0, 0.0, 650.0])
+    for i in range(n_views):
+        s = 1.0 + 0.04 * i * (1 if i % 2 else -1)
+        fx, fy = 2892.33 * W / 1600.0 * s, 2892.33 * W / 1600.0 * (2.0 - s) * 1.01
+        K = np.array([[fx, 0, W / 2.0 + 3.0 * i], [0, fy, H / 2.0 - 2.0 * i], [0, 0, 1]], np.float64)
+        if i == 0:
+            R = np.eye(3)
+            C = np.zeros(3)
+        else:
+            axis = np.array([0.35 * (1 if i % 2 else -1), 1.0, 0.25 * (-1) ** (i // 2)])
+            axis /= np.linalg.norm(axis)
+            a = 0.07 * i * (1.0 if i % 2 else -1.0)
+            Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+            R = np.eye(3) + math.sin(a) * Kx + (1 - math.cos(a)) * (Kx @ Kx)  # Rodrigues
+            roll = 0.05 * i
+            Rz = np.array([[math.cos(roll), -math.sin(roll), 0], [math.sin(roll), math.cos(roll), 0], [0, 0, 1]])
+            R = Rz @ R
+            C = np.array([0.0, 12.0 * i * (-1) ** i, -8.0 * i])  # off the orbit: up / down and towards / away from the scene
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = (P - R @ P) - R @ C
+        intr.append(K)
+        extr.append(E)
+    return np.stack(intr).astype(np.float32)[None], np.stack(extr).astype(np.float32)[None]
+
+
 def synthetic_images(n_views: int, H: int, W: int, smooth: bool = True) -> List[torch.Tensor]:
     """Seeded images in [0,1].  ``smooth`` low-pass filters the noise and shifts it per view so the matching cost
     has structure; smooth=False is i.i.d. noise (the adversarial case for rounding parity)."""

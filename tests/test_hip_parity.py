@@ -78,7 +78,7 @@ def test_nchw_to_nhwc_roundtrip():
     assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
 
 
-@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations"])
+@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations", "rig"])
 @pytest.mark.parametrize("stage", [3, 2, 1])
 def test_kernels_against_golden(case, stage):
     """Every kernel of one stage, fed the reference's own tensors (incl. its conv offsets), against the reference's
@@ -157,7 +157,7 @@ def test_kernels_against_golden(case, stage):
         assert GU.rel_err(n(dep), g[key + "depth"]) < 2e-5
 
 
-@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations"])
+@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations", "rig"])
 def test_cascade_with_reference_features(case):
     """PatchmatchNet.forward fed the reference's FeatureNet outputs and noise: whole hot path + MIOpen offset heads +
     refinement + confidence vs the reference's final outputs (north_star tolerance 1e-3 relative on depth)."""

@@ -25,7 +25,7 @@ def test_differentiable_warping_known_answers(name):
     np.testing.assert_array_equal(out == 0, ref == 0)
 
 
-@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations"])
+@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations", "rig"])
 @pytest.mark.parametrize("stage", [3, 2, 1])
 def test_stage_against_golden(case, stage):
     """Each PatchMatch stage fed the reference's own inputs reproduces every per-iteration intermediate."""
@@ -50,7 +50,7 @@ def test_stage_against_golden(case, stage):
         assert GU.rel_err(depths[it - 1], g[key + "depth_out"]) < 1e-4
 
 
-@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations"])
+@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations", "rig"])
 def test_numpy_offset_heads(case):
     g, params, kw = GU.load_case(case)
     for stage in (3, 2, 1):
@@ -65,7 +65,7 @@ def test_numpy_offset_heads(case):
             assert GU.abs_err(pr, g[f"s{stage}_propa_offsets"]) < 1e-4
 
 
-@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations"])
+@pytest.mark.parametrize("case", ["default", "variant", "counts", "dilations", "rig"])
 def test_cascade_and_confidence(case):
     """Whole cascade chained from the FeatureNet outputs (errors compound down the stages, tolerance 1e-3 as in
     BASELINE.json's north_star) and the confidence epilogue on the golden stage-1 probabilities."""
