@@ -22,6 +22,14 @@ import queue
 import sys
 import time
 
+# ONE hardware queue for this process (round 5, DESIGN_LESSONS.md lesson 45).  A forward replayed as a HIP graph while ANY other work of
+# the process runs on another hardware queue -- a second sample's replay, the next sample's eager FeatureNet, the fusion stage's kernels
+# -- came out different from the eager forward: usually in the fifth digit of a few thousand pixels, now and then entirely (measured at
+# 1600x1200: 87 of 96 bench steps with three samples in flight, 7 of 16 eval.py maps with the default flags; 0 and 0 with one hardware
+# queue; eager launches on several streams and graphs of ATen kernels are not affected; one contributor was a kernel with a scratch
+# frame, since removed, the rest is unexplained).  HIP reads the variable when the runtime initialises, i.e. before torch is imported;
+# an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 import numpy as np
 import torch
 from torch.utils.data import DataLoader

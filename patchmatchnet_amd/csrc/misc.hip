@@ -150,47 +150,77 @@ __global__ void stage_projections_kernel(const float* __restrict__ intr, const f
     const int v = i % nsrc + 1, b = (i / nsrc) % B, s = i / (nsrc * B);
     float scale = scale0;
     for (int k = 0; k < s; ++k) scale *= 2.0f;
+    // Every array below is indexed with compile-time constants only (loops fully unrolled, the pivot row exchanged by predicated
+    // swaps): the kernel must not touch SCRATCH.  Round 5: it was the one kernel of the default forward with a private-memory frame
+    // (272 bytes per lane: `A[piv][c]` with a run-time row), and forwards replayed as HIP graphs CONCURRENTLY on several streams then
+    // came out with slightly -- now and then entirely -- wrong projections (scripts/graph_overlap_probe.py: 63 of 300 rounds; none with
+    // one hardware queue, none for eager launches, none for graphs of ATen kernels).  Same operations in the same order as before.
     float P[2][16];
+#pragma unroll
     for (int w = 0; w < 2; ++w) {
         const int view = w == 0 ? 0 : v;
         const float* K = intr + ((size_t)b * V + view) * 9;
         const float* E = extr + ((size_t)b * V + view) * 16;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float k0 = r < 2 ? K[r * 3 + 0] * scale : K[r * 3 + 0];
             const float k1 = r < 2 ? K[r * 3 + 1] * scale : K[r * 3 + 1];
             const float k2 = r < 2 ? K[r * 3 + 2] * scale : K[r * 3 + 2];
+#pragma unroll
             for (int c = 0; c < 4; ++c) P[w][r * 4 + c] = (k0 * E[0 * 4 + c] + k1 * E[1 * 4 + c]) + k2 * E[2 * 4 + c];
         }
+#pragma unroll
         for (int c = 0; c < 4; ++c) P[w][12 + c] = E[12 + c];
     }
-    // inverse of P[0] in fp64
+    // inverse of P[0] in fp64: Gauss-Jordan with partial pivoting
     double A[4][8];
+#pragma unroll
     for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             A[r][c] = (double)P[0][r * 4 + c];
             A[r][4 + c] = r == c ? 1.0 : 0.0;
         }
+#pragma unroll
     for (int col = 0; col < 4; ++col) {
         int piv = col;
-        for (int r = col + 1; r < 4; ++r)
-            if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
-        for (int c = 0; c < 8; ++c) {
-            const double t = A[col][c];
-            A[col][c] = A[piv][c];
-            A[piv][c] = t;
+        double best = fabs(A[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {  // (the first row with the strictly largest magnitude, as `fabs(A[r][col]) > fabs(A[piv][col])` picks)
+            const double m = fabs(A[r][col]);
+            if (m > best) {
+                best = m;
+                piv = r;
+            }
+        }
+#pragma unroll
+        for (int r = col + 1; r < 4; ++r) {  // exchange rows col and piv
+            const bool sw = piv == r;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double lo = A[col][c], hi = A[r][c];
+                A[col][c] = sw ? hi : lo;
+                A[r][c] = sw ? lo : hi;
+            }
         }
         const double inv = 1.0 / A[col][col];
+#pragma unroll
         for (int c = 0; c < 8; ++c) A[col][c] *= inv;
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r == col) continue;
             const double f = A[r][col];
+#pragma unroll
             for (int c = 0; c < 8; ++c) A[r][c] -= f * A[col][c];
         }
     }
     float* o = rel + (((size_t)s * B + b) * nsrc + (v - 1)) * 16;
+#pragma unroll
     for (int r = 0; r < 4; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             float acc = 0.0f;
+#pragma unroll
             for (int k = 0; k < 4; ++k) acc = acc + P[1][r * 4 + k] * (float)A[k][4 + c];
             o[r * 4 + c] = acc;
         }

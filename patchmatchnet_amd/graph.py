@@ -41,7 +41,17 @@ class GraphedForward:
     samples) that is free; a pipeline that recycles its upload buffers keeps the default.  An image the kernel cannot read in place
     (not dense float32, or not 16-byte aligned) is copied into the slot and the table points there."""
 
+    _warned = False
+
     def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
+        import os
+        if os.environ.get("GPU_MAX_HW_QUEUES") != "1" and not GraphedForward._warned:
+            GraphedForward._warned = True
+            import warnings
+            warnings.warn("GraphedForward: GPU_MAX_HW_QUEUES is not 1 -- on this ROCm stack a forward replayed as a HIP graph while other "
+                          "work of the process runs on another hardware queue has been measured NOT to reproduce the eager forward bit for "
+                          "bit (DESIGN_LESSONS.md lesson 45); eval.py and bench.py set GPU_MAX_HW_QUEUES=1 before importing torch",
+                          RuntimeWarning, stacklevel=2)
         self.model, self.max_graphs, self.inputs_in_place = model, max_graphs, inputs_in_place
         self.cache: Dict[Tuple, Tuple] = {}
         self.replays = self.captures = self.evictions = 0

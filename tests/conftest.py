@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The GPU suite calls eval.main() / bench pieces IN PROCESS: the one-hardware-queue setting those programs make for themselves
+# (eval.py / bench.py, DESIGN_LESSONS.md lesson 45: a forward replayed as a HIP graph beside other GPU work of the process is only
+# bit-identical to the eager forward on ONE hardware queue) has to be in the environment before torch initialises HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

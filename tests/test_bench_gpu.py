@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--width", "640", "--height", "480", "--steps", "6", "--warmup", "2", "--samples", "3", "--roofline-steps", "4",
+SMALL = ["--width", "640", "--height", "480", "--steps", "6", "--warmup", "2", "--samples", "3", "--roofline-steps", "4", "--verify-steps", "12",
          "--no-cpu-baseline", "--steady-seconds", "0.2", "--settle-seconds", "0.2"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config", "roofline", "single_stream_eager", "steady_state"}
@@ -48,6 +48,10 @@ def test_bench_line_default_and_eager():
         line = _line(p.stdout)
         _check(line, 1)
         assert line["config"]["in_flight"] == (1 if extra else 3)
+        # the timed mode's outputs are the eager forward's, bit for bit (one hardware queue: bench.py sets it for itself)
+        assert line["config"]["hardware_queues"] == "1"
+        ver = line["outputs_verified"]
+        assert (ver is None) == bool(extra) and (extra or (ver["steps"] >= 6 and ver["steps_that_differ_from_the_eager_forward"] == 0)), ver
         # both input modes of the graph replay are on the line (in place = `value`; copied into the slot = rounds 2-4's `value`)
         other = line["value_other_input_mode"]
         assert (other is None) == bool(extra) and (extra or (other["value"] > 0 and "copied" in other["mode"]))
