@@ -11,11 +11,11 @@ Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU
 with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
 confidence maps closes the timed region, as the per-scan gather before fusion does in eval.
 
-Timed region (``value``): by default every GPU keeps THREE independent samples in flight, each on its own HIP stream and each
-forward issued as ONE HIP-graph replay (--in-flight S, patchmatchnet_amd/graph.py): the gathers sit on the vector-memory pipe,
-the convolutions on the matrix cores, the stem / aggregation on the VALU, so forwards sharing the CUs finish sooner than
-back to back (same box: 276 one at a time, 304.6 with two in flight, 310.6 with three, 298.6 with four), and the graph removes
-the ~3.5 ms of Python launch work per forward from the critical path.
+Timed region (``value``): every forward is issued as ONE HIP-graph replay (patchmatchnet_amd/graph.py), --in-flight S replay slots
+(default three) on their own HIP streams so that the launch thread stays ahead of the device -- on ONE hardware queue
+(GPU_MAX_HW_QUEUES=1, set below before torch initialises HIP): rounds 2-4 let the slots overlap on several hardware queues (+12 %),
+and round 5 found that such a replay does not reproduce the eager forward (DESIGN_LESSONS.md lesson 45).  ``outputs_verified`` on the
+line: --verify-steps further steps in exactly the timed mode, compared BIT FOR BIT with the same steps launched eagerly one at a time.
 ``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
 (``single_stream_eager`` = one sample's latency).
 
