@@ -56,7 +56,8 @@ with torch.no_grad():
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            o = layers(inputs[k])
+            for _ in range(int(os.environ.get("PMN_PROBE_REPEAT", "1"))):  # how many FeatureNet passes (= graph nodes) per graph
+                o = layers(inputs[k])
         graphs.append(g)
         outs.append(o)
     torch.cuda.synchronize()
@@ -75,5 +76,5 @@ with torch.no_grad():
                     nan += int(torch.isnan(got[k][n]).any())
                     first_bad.setdefault((k, n), []).append((r, int((got[k][n] != want[k][n]).sum()), float(d[~torch.isnan(d)].max()) if (~torch.isnan(d)).any() else -1.0))
                     break  # the first layer (in execution order) that differs
-print(f"FeatureNet alone, {S} graphs replayed concurrently x{rounds} at {W}x{H}: first deviating layer per (slot, layer):",
+print(f"FeatureNet x{os.environ.get('PMN_PROBE_REPEAT', '1')} per graph, {S} graphs replayed concurrently x{rounds} at {W}x{H}: first deviating layer per (slot, layer):",
       {k: (len(v), v[:2]) for k, v in first_bad.items()} if first_bad else "none", "| rounds with NaN:", nan)
