@@ -283,6 +283,28 @@ def cpu_baseline(H, W, n_src, model_kw, thread_counts=(8, 32, 64)):
             "reference_measured_elsewhere": REFERENCE_CPU_MEASURED}
 
 
+def several_queues_leg(args, timeout_s=240):
+    """The default command once more in a child process with GPU_MAX_HW_QUEUES=4 (no baselines, short): DESIGN_LESSONS.md lesson 45."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps", str(min(args.steps, 60)), "--warmup", "5",
+           "--verify-steps", "48", "--steady-seconds", "0", "--roofline-steps", "4", "--samples", str(args.samples), "--width",
+           str(args.width), "--height", str(args.height), "--views", str(args.views), "--in-flight", str(args.in_flight)]
+    try:
+        p = subprocess.run(cmd, env=dict(os.environ, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=timeout_s)
+        js = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not js:
+            return {"error": (p.stderr or "no line")[-200:]}
+        j = json.loads(js[-1])
+        v = j.get("outputs_verified") or {}
+        return {"hardware_queues": 4, "value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                "verified_steps": v.get("steps"), "steps_that_differ_from_the_eager_forward": v.get("steps_that_differ_from_the_eager_forward"),
+                "max_relative_depth_difference": v.get("max_relative_depth_difference"),
+                "note": "NOT a valid figure: with several hardware queues the slots' forwards overlap and most steps are not the eager "
+                        "forward's (the mode of rounds 2-4's `value`); shown for what the one-queue rule costs"}
+    except Exception as e:  # noqa: BLE001 -- an extra leg must never take the line down
+        return {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+
+
 def self_launch(n_ranks):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU, free rendezvous port on 127.0.0.1),
     rank 0 inherits stdout and prints the single JSON line; the exit code is the worst rank's."""
@@ -710,6 +732,11 @@ def main():
                     ref_gpu["this_engine_over_reference"] = round(value / ref_gpu["value"], 2)
                     ref_gpu["this_engine_single_stream_over_reference"] = round((R / eager_elapsed) / ref_gpu["value"], 2)
                 line["reference_rocm"] = ref_gpu
+        if world == 1 and not args.no_cpu_baseline and not args.eager and os.environ.get("GPU_MAX_HW_QUEUES") == "1":
+            # what the one-hardware-queue rule costs and buys, on the line: the same command in a child process with the runtime's
+            # default four queues (the mode of rounds 2-4: forwards of different slots overlap) -- its rate and how many of its
+            # verified steps are NOT the eager forward's
+            line["several_hardware_queues"] = several_queues_leg(args)
         print(json.dumps(line), flush=True)
     if launched:
         dist.barrier()
