@@ -11,11 +11,14 @@ Inputs (images, cameras) are resident in HBM before the timed region.  Multi-GPU
 with no data-path collective (weak scaling: every rank does K steps); one RCCL all-gather of the per-rank depth /
 confidence maps closes the timed region, as the per-scan gather before fusion does in eval.
 
-Timed region (``value``): every forward is issued as ONE HIP-graph replay (patchmatchnet_amd/graph.py), --in-flight S replay slots
-(default three) on their own HIP streams so that the launch thread stays ahead of the device -- on ONE hardware queue
-(GPU_MAX_HW_QUEUES=1, set below before torch initialises HIP): rounds 2-4 let the slots overlap on several hardware queues (+12 %),
-and round 5 found that such a replay does not reproduce the eager forward (DESIGN_LESSONS.md lesson 45).  ``outputs_verified`` on the
-line: --verify-steps further steps in exactly the timed mode, compared BIT FOR BIT with the same steps launched eagerly one at a time.
+Timed region (``value``): every forward is issued as ONE launch-plan replay (patchmatchnet_amd/graph.py: PlannedForward; the forward's
+~55 launches recorded once and replayed from C with plain hipLaunchKernel calls, include/pmn_hip.h pmn_plan_*), --in-flight S replay
+slots (default three) on their own HIP streams, on the runtime's default hardware queues, so that forwards of different samples overlap
+on the device.  Rounds 2-5 replayed HIP graphs instead: overlapping graph replays do not reproduce the eager forward on this ROCm stack
+(DESIGN_LESSONS.md lessons 45-46), plain launches do.  ``--launch graph`` keeps the round-5 mode (HIP-graph replay, ONE hardware
+queue: GPU_MAX_HW_QUEUES=1 is then set below before torch initialises HIP).  ``outputs_verified`` on the line: --verify-steps further
+steps in exactly the timed mode, compared BIT FOR BIT with the same steps launched eagerly one at a time; a mismatch makes the
+process exit non-zero.
 ``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
 (``single_stream_eager`` = one sample's latency).
 
@@ -43,14 +46,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# ONE hardware queue for this process (round 5, DESIGN_LESSONS.md lesson 45).  A forward replayed as a HIP graph while ANY other work of
-# the process runs on another hardware queue -- a second sample's replay, the next sample's eager FeatureNet, the fusion stage's kernels
-# -- came out different from the eager forward: usually in the fifth digit of a few thousand pixels, now and then entirely (measured at
-# 1600x1200: 87 of 96 bench steps with three samples in flight, 7 of 16 eval.py maps with the default flags; 0 and 0 with one hardware
-# queue; eager launches on several streams and graphs of ATen kernels are not affected; one contributor was a kernel with a scratch
-# frame, since removed, the rest is unexplained).  HIP reads the variable when the runtime initialises, i.e. before torch is imported;
-# an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+# --launch graph (round 5's mode) needs ONE hardware queue for the process: a forward replayed as a HIP graph while any other work of
+# the process runs on another hardware queue came out different from the eager forward (DESIGN_LESSONS.md lesson 45).  HIP reads the
+# variable when the runtime initialises, i.e. before torch is imported, hence the look at argv here.  The default mode (launch plans:
+# plain launches) runs on whatever the runtime creates.
+if "graph" in [a.split("=")[-1] for i, a in enumerate(sys.argv) if a.startswith("--launch=") or (i and sys.argv[i - 1] == "--launch")]:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -283,28 +284,6 @@ def cpu_baseline(H, W, n_src, model_kw, thread_counts=(8, 32, 64)):
             "reference_measured_elsewhere": REFERENCE_CPU_MEASURED}
 
 
-def several_queues_leg(args, timeout_s=240):
-    """The default command once more in a child process with GPU_MAX_HW_QUEUES=4 (no baselines, short): DESIGN_LESSONS.md lesson 45."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps", str(min(args.steps, 60)), "--warmup", "5",
-           "--verify-steps", "48", "--steady-seconds", "0", "--roofline-steps", "4", "--samples", str(args.samples), "--width",
-           str(args.width), "--height", str(args.height), "--views", str(args.views), "--in-flight", str(args.in_flight)]
-    try:
-        p = subprocess.run(cmd, env=dict(os.environ, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, timeout=timeout_s)
-        js = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-        if p.returncode != 0 or not js:
-            return {"error": (p.stderr or "no line")[-200:]}
-        j = json.loads(js[-1])
-        v = j.get("outputs_verified") or {}
-        return {"hardware_queues": 4, "value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
-                "verified_steps": v.get("steps"), "steps_that_differ_from_the_eager_forward": v.get("steps_that_differ_from_the_eager_forward"),
-                "max_relative_depth_difference": v.get("max_relative_depth_difference"),
-                "note": "NOT a valid figure: with several hardware queues the slots' forwards overlap and most steps are not the eager "
-                        "forward's (the mode of rounds 2-4's `value`); shown for what the one-queue rule costs"}
-    except Exception as e:  # noqa: BLE001 -- an extra leg must never take the line down
-        return {"error": f"{type(e).__name__}: {str(e)[:160]}"}
-
-
 def self_launch(n_ranks):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU, free rendezvous port on 127.0.0.1),
     rank 0 inherits stdout and prints the single JSON line; the exit code is the worst rank's."""
@@ -351,7 +330,10 @@ def main():
     ap.add_argument("--views", type=int, default=5, help="number of SOURCE views (reference eval.py --num_views)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3,
-                    help="independent samples in flight per GPU: one HIP stream + one HIP-graph replay slot each (1 = one stream)")
+                    help="independent samples in flight per GPU: one HIP stream + one replay slot each (1 = one stream)")
+    ap.add_argument("--launch", choices=("plan", "graph"), default="plan",
+                    help="plan = the forward recorded as a launch plan and replayed from C with plain launches (default); graph = round "
+                         "5's HIP-graph replay on one hardware queue")
     ap.add_argument("--copy-inputs", action="store_true",
                     help="graph replay reads copies of all six images in the slot's static buffers (rounds 2-4) instead of the samples in place")
     ap.add_argument("--eager", action="store_true",
@@ -363,7 +345,7 @@ def main():
     ap.add_argument("--settle-seconds", type=float, default=1.0,
                     help="untimed replays after the W warm-up steps until the clocks / caches have settled (the timed region is still "
                          "exactly K steps); 0 = only the W warm-up steps")
-    ap.add_argument("--verify-steps", type=int, default=48,
+    ap.add_argument("--verify-steps", type=int, default=96,
                     help="steps of the timed mode whose outputs are compared bit for bit with eager forwards under the same seeds (0 = skip)")
     ap.add_argument("--steady-seconds", type=float, default=2.0,
                     help="length of the extra steady-state pass reported as `steady_state` (0 = skip)")
@@ -507,9 +489,11 @@ def main():
         def timed_in_flight(copy_inputs=args.copy_inputs, publish=True):
             """Returns the elapsed time, or None when some rank could not capture its graphs (decided collectively before the
             timed region, so that every rank then takes the same path)."""
-            from patchmatchnet_amd.graph import GraphedForward
+            from patchmatchnet_amd.graph import GraphedForward, PlannedForward
             streams = [torch.cuda.Stream(device) for _ in range(S)]
-            slots = [GraphedForward(model, inputs_in_place=not copy_inputs) for _ in range(S)]
+            Slot = PlannedForward if args.launch == "plan" else GraphedForward
+            slots = [Slot(model, inputs_in_place=not copy_inputs) for _ in range(S)]
+            region.setdefault("slots", slots)
 
             def replay(i):
                 k, s = i % S, samples[i % len(samples)]
@@ -590,8 +574,8 @@ def main():
             torch.cuda.synchronize()
             del kept
             verified = {"steps": V, "steps_that_differ_from_the_eager_forward": bad, "max_relative_depth_difference": worst,
-                        "what": f"{V} steps in the timed mode ({S} in flight, graph replay, seeded draws) against the same steps one at a "
-                                "time, launched from Python: depth and confidence compared bit for bit"}
+                        "what": f"{V} steps in the timed mode ({S} in flight, {args.launch} replay, seeded draws) against the same steps one "
+                                "at a time, launched from Python: depth and confidence compared bit for bit"}
             bad_all = reduce_scalar(float(bad), dist.ReduceOp.SUM)
             verified["steps_that_differ_all_ranks"] = int(bad_all)
 
@@ -658,11 +642,17 @@ def main():
                 traffic = per_step
             except KeyError:
                 traffic = None
+        plan_launches = 0
+        if args.launch == "plan" and "slots" in region:
+            for handle, _, _ in region["slots"][0].cache.values():
+                plan_launches = handle.count
+        # every untimed step before the K timed ones: the W asked for (at least one per slot: its recording) plus the settle pass
+        untimed = max(args.warmup, S if not args.eager else 0) + extra_warmup[0]
         baseline_config = {(1200, 1600, 5): "BASELINE configs[1]", (1056, 1920, 7): "BASELINE configs[2]",
                            (2048, 3072, 10): "BASELINE configs[4], one GPU's share"}.get((H, W, n_src), "not a BASELINE config")
         line = {
             "metric": f"depth-maps/sec at {W}x{H} N={n_src} src views", "value": round(value, 4), "unit": "depth-maps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": untimed, "warmup_requested": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PatchmatchNet.forward, {W}x{H}, N={n_src} source views, iters (1,2,2), B=1 "
                                    f"({baseline_config}); ref views sharded 1/rank", "weights": weights,
@@ -674,14 +664,16 @@ def main():
                        "scene": "photo-consistent rendered surface (tests/synth.render_scene), one texture seed per sample"
                                 if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
-                       "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                       "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (GPU_MAX_HW_QUEUES unset: 4)"),
                        "ranks_seen": ranks_seen, "backend": dist.get_backend() if launched else "none (single process, no process group)",
                        "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 4),
                        "ms_per_step_rank_max": round(elapsed / args.steps * 1e3, 4),
                        "numa": numa_notes,
-                       "untimed_steps_before_the_timed_region": max(args.warmup, S if not args.eager else 0) + extra_warmup[0],
+                       "untimed_steps_before_the_timed_region": untimed,
                        "in_flight": S, "launch": launch_note or ("python, one stream" if args.eager else
-                       f"HIP-graph replay, {S} sample(s) in flight on {S} HIP stream(s) per GPU; images "
+                       ("launch-plan replay (plain hipLaunchKernel calls from C, pmn_plan_launch: %d launches per forward)" % plan_launches
+                        if args.launch == "plan" else "HIP-graph replay") +
+                       f", {S} sample(s) in flight on {S} HIP stream(s) per GPU; images "
                        + ("copied into the slot's static buffers" if args.copy_inputs else
                           "read in place through a device table of addresses (pmn_stem_f16s_views)"))},
             "value_other_input_mode": None if other_mode is None else {
@@ -732,15 +724,13 @@ def main():
                     ref_gpu["this_engine_over_reference"] = round(value / ref_gpu["value"], 2)
                     ref_gpu["this_engine_single_stream_over_reference"] = round((R / eager_elapsed) / ref_gpu["value"], 2)
                 line["reference_rocm"] = ref_gpu
-        if world == 1 and not args.no_cpu_baseline and not args.eager and os.environ.get("GPU_MAX_HW_QUEUES") == "1":
-            # what the one-hardware-queue rule costs and buys, on the line: the same command in a child process with the runtime's
-            # default four queues (the mode of rounds 2-4: forwards of different slots overlap) -- its rate and how many of its
-            # verified steps are NOT the eager forward's
-            line["several_hardware_queues"] = several_queues_leg(args)
         print(json.dumps(line), flush=True)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+    if verified is not None and verified.get("steps_that_differ_all_ranks", 0) > 0:
+        # the line is printed (the numbers are what they are), but a timed mode whose outputs are not the eager forward's is a failure
+        raise SystemExit(f"bench.py: {verified['steps_that_differ_all_ranks']} of {verified['steps']} verified steps differ from the eager forward")
 
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@ nn.DataParallel), each scan's maps are all-gathered over RCCL, and every rank th
 one HIP kernel launch per view (pmn_fuse_view) instead of numpy/cv2; rank 0 stitches the per-rank point lists into fused.ply.
 Disk and PCIe traffic is taken off the critical path: decoded images go through pinned memory on a copy stream one sample
 ahead, finished maps leave through pinned buffers on a second copy stream and are written by a pool of writer threads; the
-forward itself is one HIP-graph replay per sample, with --in_flight samples overlapping on their own streams.
+forward itself is one launch-plan replay per sample (its ~55 launches recorded once, replayed from C), with --in_flight samples
+overlapping on their own streams.
 """
 import argparse
 import concurrent.futures
@@ -22,14 +23,12 @@ import queue
 import sys
 import time
 
-# ONE hardware queue for this process (round 5, DESIGN_LESSONS.md lesson 45).  A forward replayed as a HIP graph while ANY other work of
-# the process runs on another hardware queue -- a second sample's replay, the next sample's eager FeatureNet, the fusion stage's kernels
-# -- came out different from the eager forward: usually in the fifth digit of a few thousand pixels, now and then entirely (measured at
-# 1600x1200: 87 of 96 bench steps with three samples in flight, 7 of 16 eval.py maps with the default flags; 0 and 0 with one hardware
-# queue; eager launches on several streams and graphs of ATen kernels are not affected; one contributor was a kernel with a scratch
-# frame, since removed, the rest is unexplained).  HIP reads the variable when the runtime initialises, i.e. before torch is imported;
-# an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+# --hip_graph 2 (round 5's HIP-graph replay) needs ONE hardware queue for the process: a forward replayed as a HIP graph while any other
+# work of the process runs on another hardware queue came out different from the eager forward (DESIGN_LESSONS.md lesson 45).  HIP reads
+# the variable when the runtime initialises, i.e. before torch is imported, hence the look at argv here.  The default (--hip_graph 1 =
+# launch plans: plain launches replayed from C) runs on whatever queues the runtime creates.
+if any(a == "--hip_graph=2" or (i and sys.argv[i - 1] == "--hip_graph" and a == "2") for i, a in enumerate(sys.argv)):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 import numpy as np
 import torch
 from torch.utils.data import DataLoader
@@ -37,7 +36,7 @@ from torch.utils.data import DataLoader
 import patchmatchnet_amd as P
 from patchmatchnet_amd import dist as pdist
 from patchmatchnet_amd import fusion
-from patchmatchnet_amd.graph import GraphedForward
+from patchmatchnet_amd.graph import GraphedForward, PlannedForward
 from patchmatchnet_amd.data_io import (image_shape, read_cam_file, read_image, read_image_u8, read_map, read_pair_file, save_image,
                                        save_map)
 from patchmatchnet_amd.mvs import MVSDataset, MVSViewDataset
@@ -377,15 +376,16 @@ def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
     t_stage = time.time()
     model = load_model(args, device)
     t_loaded = time.time()
-    # --hip_graph: one HIP-graph replay per sample instead of ~55 Python-issued launches -- the launch thread is what the
-    # uploads and the writer threads compete with; --in_flight S: S samples in flight, each on its own HIP stream with its own
-    # replay slot, so that the gathers of one sample (vector-memory pipe) share the CUs with the convolutions of the other
-    # (matrix cores).  Same maps bit for bit (patchmatchnet_amd/graph.py, tests/test_eval_gpu.py).
+    # --hip_graph 1: one launch-plan replay per sample (pmn_plan_launch: the forward's launches recorded once and re-issued from C)
+    # instead of ~55 Python-issued launches -- the launch thread is what the uploads and the writer threads compete with;
+    # --in_flight S: S samples in flight, each on its own HIP stream with its own replay slot, so that the gathers of one sample
+    # (vector-memory pipe) share the CUs with the convolutions of the other (matrix cores).  Same maps bit for bit
+    # (patchmatchnet_amd/graph.py, tests/test_eval_gpu.py).  --hip_graph 2: round 5's HIP-graph replay (one hardware queue).
     main_stream = torch.cuda.current_stream(device)
     n_slots = max(args.in_flight, 1) if args.hip_graph else 1
     streams = [torch.cuda.Stream(device) for _ in range(n_slots)] if args.hip_graph else [main_stream]
     if args.hip_graph:
-        slots = [GraphedForward(model) for _ in range(n_slots)]
+        slots = [(GraphedForward if args.hip_graph == 2 else PlannedForward)(model) for _ in range(n_slots)]
     else:
         slots = [lambda *a, **kw: model(*a, **kw)[:2]]
     turn = [0]
@@ -901,9 +901,11 @@ def build_parser():
                    help="--output_type both: 1 = a finished scan is filtered + fused on a worker thread with its own HIP stream while "
                         "the next scan's inference runs; 0 = inline on the launch thread (same files, same bytes)")
     p.add_argument("--in_flight", type=int, default=2,
-                   help="samples in flight per GPU (HIP streams, one graph-replay slot each); needs --hip_graph 1")
-    p.add_argument("--hip_graph", type=int, default=1,
-                   help="1: replay the forward as a HIP graph (one launch per sample); 0: issue every kernel from Python")
+                   help="samples in flight per GPU (HIP streams, one replay slot each); needs --hip_graph 1 or 2")
+    p.add_argument("--hip_graph", type=int, default=1, choices=(0, 1, 2),
+                   help="1: replay the forward as a launch plan (one library call per sample: its launches recorded once, re-issued "
+                        "from C with plain hipLaunchKernel calls); 2: round 5's HIP-graph replay (sets GPU_MAX_HW_QUEUES=1: overlapping "
+                        "graph replays are not bit-exact on several hardware queues); 0: issue every kernel from Python")
     p.add_argument("--stream_views", type=int, default=1,
                    help="1: with --feature_cache, decode every view once through ONE DataLoader over all scans, in first-use order, "
                         "overlapped with the forwards; 0: two passes per scan (decode + encode all views, then the samples)")

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 19
+#define PMN_ABI_VERSION 20
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -294,6 +294,39 @@ int pmn_fuse_view(const float *maps, long long slot_stride, int ref_slot, const 
 int pmn_pack_points(const unsigned char *final_mask, const float *xyz, const void *image_hwc, int image_is_float, int H, int W,
                     unsigned char *records, long long capacity_points, long long *cursor, int *view_count, long long *scratch,
                     void *stream);
+
+/* ABI 20.  Refinement's input normalisation (reference models/net.py:104-106): out = (depth - depth_min[b]) / (depth_max[b] -
+ * depth_min[b]) over n floats per batch element, IEEE subtraction and correctly rounded division = the bits of the torch expression.
+ * With it a whole forward consists of launches of this library only, which is what makes it recordable as a launch plan. */
+int pmn_normalize_depth(const float *depth, const float *depth_min, const float *depth_max, int B, int n, float *out,
+                        void *stream);
+
+/* ---- ABI 20: launch plans -------------------------------------------------------------------------------------------------------
+ * A plan is a recorded list of kernel launches that pmn_plan_launch replays on a stream with plain hipLaunchKernel calls from C: the
+ * whole forward (reference models/net.py:176-301, the body of the loop at eval.py:56-65) as ONE library call per sample, without a
+ * HIP graph.  (Rounds 2-5 replayed a captured HIP graph; on this ROCm stack a graph replay that overlaps other work of the process
+ * on another hardware queue does not reproduce the eager forward bit for bit, plain launches on several streams do:
+ * DESIGN_LESSONS.md lessons 45-46.)
+ *
+ *   pmn_plan_create(&plan)
+ *   pmn_plan_begin(plan)          from now on every pmn_* entry point called BY THIS THREAD validates its arguments as usual but
+ *   ... pmn_* calls ...           appends its launches (kernel, grid, LDS size, a copy of the by-value arguments, neighbour tables
+ *   pmn_plan_end(plan)            included) to the plan instead of enqueuing them; their `stream` argument is ignored
+ *   pmn_plan_launch(plan, stream) enqueues the recorded launches, in order, on `stream`; any number of times, from any thread
+ *   pmn_plan_destroy(plan)
+ *
+ * The plan holds the DEVICE addresses that were passed while recording: the caller keeps those buffers alive and in place for the
+ * life of the plan and feeds new inputs by writing into them (or into the device address tables of pmn_warp_correlate_views /
+ * pmn_stem_f16s_views) before each launch, on the same stream.  One recording per thread at a time; a plan is recorded once.
+ * pmn_plan_count = number of recorded launches; pmn_plan_kernel_name(plan, i) = the i-th kernel's symbol name (diagnostics).
+ * Like every entry point, none of these synchronises, allocates device memory or copies. */
+int pmn_plan_create(void **plan_out);
+int pmn_plan_begin(void *plan);
+int pmn_plan_end(void *plan);
+int pmn_plan_count(const void *plan);
+const char *pmn_plan_kernel_name(const void *plan, int index);
+int pmn_plan_launch(const void *plan, void *stream);
+int pmn_plan_destroy(void *plan);
 
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -56,6 +56,14 @@ SIGNATURES = {
     "pmn_differentiable_warping": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _s],
     "pmn_fuse_view": [_fp, ctypes.c_longlong, _i, _hp, _hp, _i, _fp, _i, _i, _f, _f, _i, _f, _fp, _fp, _fp, _ip, _s],
     "pmn_pack_points": [_fp, _fp, _fp, _i, _i, _i, _fp, ctypes.c_longlong, _fp, _ip, _fp, _s],
+    "pmn_normalize_depth": [_fp, _fp, _fp, _i, _i, _fp, _s],
+    "pmn_plan_create": [ctypes.POINTER(ctypes.c_void_p)],
+    "pmn_plan_begin": [_hp],
+    "pmn_plan_end": [_hp],
+    "pmn_plan_count": [_hp],
+    "pmn_plan_kernel_name": [_hp, _i],
+    "pmn_plan_launch": [_hp, _s],
+    "pmn_plan_destroy": [_hp],
 }
 
 # libpmn_hip_experimental.so only (include/pmn_hip_experimental.h; `make -C patchmatchnet_amd/csrc EXPERIMENTAL=1`)
@@ -106,7 +114,7 @@ def lib() -> ctypes.CDLL:
             except AttributeError as e:
                 raise PmnError(f"libpmn_hip.so does not export {name}") from e
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == "pmn_error_string" else ctypes.c_int
+            fn.restype = ctypes.c_char_p if name in ("pmn_error_string", "pmn_plan_kernel_name") else ctypes.c_int
         if L.pmn_abi_version() != ABI_VERSION:
             raise PmnError(f"libpmn_hip.so ABI {L.pmn_abi_version()} != expected {ABI_VERSION}: rebuild")
         _LIB = L

@@ -347,11 +347,11 @@ static int launch_agg_q4(const AggArgs& a, hipStream_t s) {
     const dim3 grid((a.h * a.w + npx - 1) / npx, a.B), block(npx * DQ);
     // the cascade's hypothesis counts (8, 16, 32, 64) share the tap sets inside the pixel's lane group; other D % 4 == 0: every thread
     // forms its own
-    if (DQ == 2) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 2>), grid, block, 0, s, a);
-    else if (DQ == 4) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 4>), grid, block, 0, s, a);
-    else if (DQ == 8) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 8>), grid, block, 0, s, a);
-    else if (DQ == 16) hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((aggregate_regress_q4_kernel<KMAX, 0>), grid, block, 0, s, a);
+    if (DQ == 2) PMN_LAUNCH((aggregate_regress_q4_kernel<KMAX, 2>), grid, block, 0, s, a);
+    else if (DQ == 4) PMN_LAUNCH((aggregate_regress_q4_kernel<KMAX, 4>), grid, block, 0, s, a);
+    else if (DQ == 8) PMN_LAUNCH((aggregate_regress_q4_kernel<KMAX, 8>), grid, block, 0, s, a);
+    else if (DQ == 16) PMN_LAUNCH((aggregate_regress_q4_kernel<KMAX, 16>), grid, block, 0, s, a);
+    else PMN_LAUNCH((aggregate_regress_q4_kernel<KMAX, 0>), grid, block, 0, s, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -360,7 +360,7 @@ template <int KMAX, int DL>
 static int launch_agg_dl(const AggArgs& a, hipStream_t s) {
     constexpr int NPX = PMN_BLOCK / DL;
     const dim3 grid((a.h * a.w + NPX - 1) / NPX, a.B), block(PMN_BLOCK);
-    hipLaunchKernelGGL((aggregate_regress_kernel<KMAX, DL>), grid, block, 0, s, a);
+    PMN_LAUNCH((aggregate_regress_kernel<KMAX, DL>), grid, block, 0, s, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

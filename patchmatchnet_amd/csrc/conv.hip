@@ -281,7 +281,7 @@ static int launch_tiled_impl(const float* in, const float* w, const float* shift
     auto kern = conv_tiled_kernel<CIN, CC, COUT, COUTP, K, S, OUT_NCHW, UP>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + 15) / 16);
-    hipLaunchKernelGGL(kern, dim3(blocks, COUTP / COUT), dim3(PMN_BLOCK), lds, st, in, w, shift, up, out, a);
+    PMN_LAUNCH(kern, dim3(blocks, COUTP / COUT), dim3(PMN_BLOCK), lds, st, in, w, shift, up, out, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -295,12 +295,12 @@ static int launch_conv(const float* in, const float* w, const float* shift, cons
     if (pix >= 1500000L) {
         const int wg = (a.Wo + 3) / 4;
         const long thr = (long)a.N * a.Ho * wg;
-        hipLaunchKernelGGL((conv_kernel<CIN, COUT_T, K, S, 4, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
+        PMN_LAUNCH((conv_kernel<CIN, COUT_T, K, S, 4, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
                            dim3(PMN_BLOCK), 0, st, in, w, shift, up, out, a);
     } else {
         const int wg = (a.Wo + 1) / 2;
         const long thr = (long)a.N * a.Ho * wg;
-        hipLaunchKernelGGL((conv_kernel<CIN, COUT_T, K, S, 2, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
+        PMN_LAUNCH((conv_kernel<CIN, COUT_T, K, S, 2, IN_NCHW, OUT_NCHW>), dim3((thr + PMN_BLOCK - 1) / PMN_BLOCK, gy.y),
                            dim3(PMN_BLOCK), 0, st, in, w, shift, up, out, a);
     }
     PMN_CHECK_LAUNCH();
@@ -421,7 +421,7 @@ extern "C" int pmn_stem(const float* img, const float* w0, const float* s0, cons
                         int N, int H, int W, void* stream) {
     if (!img || !w0 || !s0 || !w1 || !s1 || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
     const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, w0, s0, w1, s1, out, N, H, W);
+    PMN_LAUNCH(stem_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, w0, s0, w1, s1, out, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -541,7 +541,7 @@ extern "C" int pmn_fpn_tail(const float* x, const float* up, const float* w_in, 
     if (!x || !up || !w_in || !b_in || !w_out || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMN_ERR_ARG;
     if (cin != 16 || cmid != 64 || cout != 16) return PMN_ERR_SHAPE;
     const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL((fpn_tail_kernel<16, 64, 16>), dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, x, up, w_in, b_in,
+    PMN_LAUNCH((fpn_tail_kernel<16, 64, 16>), dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, x, up, w_in, b_in,
                        w_out, out, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -673,7 +673,7 @@ static int launch_fpn_level(const float* x, const float* u, const float* w, cons
     auto kern = fpn_level_kernel<CIN, COUT, CA, UP>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(PMN_BLOCK), lds, st, x, u, w, b, outA, outB, N, H, W);
+    PMN_LAUNCH(kern, dim3(blocks), dim3(PMN_BLOCK), lds, st, x, u, w, b, outA, outB, N, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -751,7 +751,7 @@ extern "C" int pmn_deconv3x3s2(const float* in, const float* weights, const floa
     if (!in || !weights || !shift || !out || N < 1 || Hi < 1 || Wi < 1) return PMN_ERR_ARG;
     if (cin != 8 || cout != 8) return PMN_ERR_SHAPE;
     const size_t total = (size_t)N * Hi * Wi * 4;
-    hipLaunchKernelGGL((deconv3x3s2_kernel<8, 8>), dim3((unsigned)((total + PMN_BLOCK - 1) / PMN_BLOCK)), dim3(PMN_BLOCK), 0,
+    PMN_LAUNCH((deconv3x3s2_kernel<8, 8>), dim3((unsigned)((total + PMN_BLOCK - 1) / PMN_BLOCK)), dim3(PMN_BLOCK), 0,
                        (hipStream_t)stream, in, weights, shift, out, N, Hi, Wi, relu);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

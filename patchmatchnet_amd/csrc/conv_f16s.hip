@@ -273,7 +273,7 @@ static int launch_f16s(const float* in, const void* w, const float* shift, float
     if ((size_t)a.H * a.W * CIN >= ((size_t)1 << 30)) return PMN_ERR_SHAPE;  // the kernel addresses one image with a 32-bit offset
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f16x8*>(w), shift, out, a);
+    PMN_LAUNCH(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f16x8*>(w), shift, out, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -526,10 +526,10 @@ extern "C" int pmn_stem_f16s(const float* img, const float* w0, const float* s0,
     const int blocks = N * ((W + TS - 1) / TS) * ((H + TH - 1) / TH);
     // aligned float4 staging needs 16-byte aligned image rows: W % 4 == 0 and a 16-byte aligned base
     if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0)
-        hipLaunchKernelGGL((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+        PMN_LAUNCH((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
     else
-        hipLaunchKernelGGL((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
+        PMN_LAUNCH((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, nullptr, 1);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -547,10 +547,10 @@ extern "C" int pmn_stem_f16s_views(const float* const* img_table, int views, con
     const int N = views * B;
     const int blocks = N * ((W + TS - 1) / TS) * ((H + TH - 1) / TH);
     if (W % 4 == 0)
-        hipLaunchKernelGGL((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+        PMN_LAUNCH((stem_f16s_kernel<true, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
     else
-        hipLaunchKernelGGL((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
+        PMN_LAUNCH((stem_f16s_kernel<false, PMN_STEM_TH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, w0, s0,
                            reinterpret_cast<const f16x8*>(w1a), s1, out, N, H, W, img_table, B);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

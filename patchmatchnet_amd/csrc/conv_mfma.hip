@@ -191,7 +191,7 @@ static int launch_mfma(const float* in, const float* w, const float* shift, floa
     auto kern = conv_mfma_kernel<CIN, CC, COUT, K, S, DIL, NW, PG, D, PLANAR>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((a.Wo + 15) / 16) * ((a.Ho + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, out_b,
+    PMN_LAUNCH(kern, dim3(blocks), dim3(64 * NW), lds, st, in, reinterpret_cast<const float4*>(w), shift, out, out_b,
                        a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino16_kernel(const float* __rest
 template <int C>
 static int launch_wino(const float* in, const float* w, const float* shift, float* out, WinoArgs a, hipStream_t st) {
     const int blocks = a.N * ((a.W + 15) / 16) * ((a.H + 7) / 8);
-    hipLaunchKernelGGL(conv_wino_kernel<C>, dim3(blocks), dim3(256), 0, st, in,
+    PMN_LAUNCH(conv_wino_kernel<C>, dim3(blocks), dim3(256), 0, st, in,
                        reinterpret_cast<const float4*>(w), shift, out, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -325,7 +325,7 @@ extern "C" int pmn_conv3x3_wino(const float* in, const float* weights, const flo
     if (C == 32) return launch_wino<32>(in, weights, shift, out, a, st);
     if (C == 16) {
         const int blocks = N * ((W + 15) / 16) * ((H + 15) / 16);
-        hipLaunchKernelGGL(conv_wino16_kernel, dim3(blocks), dim3(256), 0, st, in, reinterpret_cast<const float4*>(weights), shift, out, a);
+        PMN_LAUNCH(conv_wino16_kernel, dim3(blocks), dim3(256), 0, st, in, reinterpret_cast<const float4*>(weights), shift, out, a);
         PMN_CHECK_LAUNCH();
         return PMN_OK;
     }
@@ -527,7 +527,7 @@ static int launch_w5(const float* in, const float* w, const float* shift, float*
     auto kern = conv5x5s2_wino_kernel<CIN, COUT>;
     if (lds > 48 * 1024 && pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = a.N * ((Wo + 15) / 16) * ((Ho + 4 * NG - 1) / (4 * NG));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo,
+    PMN_LAUNCH(kern, dim3(blocks), dim3(256), lds, st, in, reinterpret_cast<const f32x2*>(w), shift, out, a, Ho, Wo,
                        CIN / 8);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

@@ -537,7 +537,7 @@ static int launch_corr_mfma(GatherArgs& a, hipStream_t stream) {
         const int rc = pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc != PMN_OK) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(threads), lds, stream, a);
+    PMN_LAUNCH(kern, dim3(a.ntiles, a.B), dim3(threads), lds, stream, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

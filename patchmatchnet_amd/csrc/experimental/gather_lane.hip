@@ -581,7 +581,7 @@ static int launch_lane_wps(GatherArgs& a, unsigned long long* keys, hipStream_t 
             return PMN_ERR_LAUNCH;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg, 1, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, nunits, keys, g_lane_dbg);
+    PMN_LAUNCH(kern, dim3(nwg, 1, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, nunits, keys, g_lane_dbg);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -602,7 +602,7 @@ static int run_lane(GatherArgs& a, bool pixelwise, hipStream_t stream) {
     if (hipMemsetAsync(keys, 0, nkeys * 8, stream) != hipSuccess) return PMN_ERR_LAUNCH;
     int rc = launch_lane<C, G, DCH, MODE_VW>(a, keys, stream);
     if (rc != PMN_OK) return rc;
-    hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, stream, keys, a.vw_out,
+    PMN_LAUNCH(unpack_keys_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, stream, keys, a.vw_out,
                        a.vw_argmax, nkeys);
     PMN_CHECK_LAUNCH();
     GatherArgs a2 = a;

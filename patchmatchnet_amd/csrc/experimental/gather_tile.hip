@@ -451,7 +451,7 @@ static int launch_tile(GatherArgs& a, hipStream_t stream) {
                 return (int)PMN_ERR_LAUNCH;
             lds_set = lds;
         }
-        hipLaunchKernelGGL(kern, dim3(a.ntiles, chunks, a.B), dim3(PMN_BLOCK), lds, stream, a, cap);
+        PMN_LAUNCH(kern, dim3(a.ntiles, chunks, a.B), dim3(PMN_BLOCK), lds, stream, a, cap);
         PMN_CHECK_LAUNCH();
         return (int)PMN_OK;
     };

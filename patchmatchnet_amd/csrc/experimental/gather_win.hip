@@ -633,7 +633,7 @@ static int launch_views(GatherArgs& a, hipStream_t stream) {
             return PMN_ERR_LAUNCH;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, (a.D + 7) / 8, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, g_win_dbg);
+    PMN_LAUNCH(kern, dim3(a.ntiles, (a.D + 7) / 8, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, g_win_dbg);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -661,7 +661,7 @@ static int launch_pixelwise(GatherArgs& a, hipStream_t stream) {
             return PMN_ERR_LAUNCH;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, 1, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, g_win_dbg);
+    PMN_LAUNCH(kern, dim3(a.ntiles, 1, a.B), dim3(PMN_BLOCK), lds, stream, a, cap, g_win_dbg);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

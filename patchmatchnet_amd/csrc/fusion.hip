@@ -149,7 +149,7 @@ extern "C" int pmn_fuse_view(const float* maps, long long slot_stride, int ref_s
         a.src_w[i] = src_hw_host ? src_hw_host[2 * i + 1] : W;
         if (a.src_h[i] < 1 || a.src_w[i] < 1 || slot_stride < 2LL * a.src_h[i] * a.src_w[i]) return PMN_ERR_ARG;
     }
-    hipLaunchKernelGGL(fuse_view_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
+    PMN_LAUNCH(fuse_view_kernel, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
@@ -290,11 +290,11 @@ extern "C" int pmn_pack_points(const unsigned char* final_mask, const float* xyz
     const long long nb = (n + PMN_PACK_BLOCK - 1) / PMN_PACK_BLOCK;
     if (nb > 0x7fffffffLL) return PMN_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pack_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, n, scratch);
+    PMN_LAUNCH(pack_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, n, scratch);
     PMN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, scratch, (int)nb, cursor, capacity_points, view_count);
+    PMN_LAUNCH(pack_scan_kernel, dim3(1), dim3(1024), 0, st, scratch, (int)nb, cursor, capacity_points, view_count);
     PMN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pack_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, xyz, image_hwc, image_is_float, n,
+    PMN_LAUNCH(pack_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, final_mask, xyz, image_hwc, image_is_float, n,
                        (const long long*)scratch, records);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

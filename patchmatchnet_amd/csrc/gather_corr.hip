@@ -868,9 +868,9 @@ static int launch_pixelwise_wave(GatherArgs& a, hipStream_t stream) {
     a.ntiles = (a.h * a.w + NPIX - 1) / NPIX;
     const size_t lds = (size_t)2 * MLP_LDS_FLOATS * 4 + (size_t)NPIX * PS * 4;
     if (a.D == 64) {
-        hipLaunchKernelGGL((pixelwise_wave_kernel<PW, true>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
+        PMN_LAUNCH((pixelwise_wave_kernel<PW, true>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((pixelwise_wave_kernel<PW, false>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
+        PMN_LAUNCH((pixelwise_wave_kernel<PW, false>), dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     }
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -894,7 +894,7 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
         const int rc = pmn_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc != PMN_OK) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
+    PMN_LAUNCH(kern, dim3(a.ntiles, a.B), dim3(PMN_BLOCK), lds, stream, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

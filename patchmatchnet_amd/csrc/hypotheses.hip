@@ -322,14 +322,14 @@ extern "C" int pmn_init_hypotheses(const float* noise, const float* depth, int d
     const dim3 grid((h * w + bs - 1) / bs, B), block(bs);
     hipStream_t s = (hipStream_t)stream;
     // the cascade's own combinations (patchmatch_num_sample / propagate_neighbors of the released models) take the fixed kernel
-    if (noise && K == 16) hipLaunchKernelGGL((init_hypotheses_fixed_kernel<64, 48, 16>), grid, block, 0, s, a);
-    else if (!noise && num_sample == 16 && K == 16) hipLaunchKernelGGL((init_hypotheses_fixed_kernel<32, 16, 16>), grid, block, 0, s, a);
-    else if (!noise && num_sample == 8 && K == 8) hipLaunchKernelGGL((init_hypotheses_fixed_kernel<16, 8, 8>), grid, block, 0, s, a);
-    else if (!noise && num_sample == 8 && K == 0) hipLaunchKernelGGL((init_hypotheses_fixed_kernel<8, 8, 0>), grid, block, 0, s, a);
-    else if (D <= 8) hipLaunchKernelGGL(init_hypotheses_kernel<8>, grid, block, 0, s, a);
-    else if (D <= 16) hipLaunchKernelGGL(init_hypotheses_kernel<16>, grid, block, 0, s, a);
-    else if (D <= 32) hipLaunchKernelGGL(init_hypotheses_kernel<32>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(init_hypotheses_kernel<64>, grid, block, 0, s, a);
+    if (noise && K == 16) PMN_LAUNCH((init_hypotheses_fixed_kernel<64, 48, 16>), grid, block, 0, s, a);
+    else if (!noise && num_sample == 16 && K == 16) PMN_LAUNCH((init_hypotheses_fixed_kernel<32, 16, 16>), grid, block, 0, s, a);
+    else if (!noise && num_sample == 8 && K == 8) PMN_LAUNCH((init_hypotheses_fixed_kernel<16, 8, 8>), grid, block, 0, s, a);
+    else if (!noise && num_sample == 8 && K == 0) PMN_LAUNCH((init_hypotheses_fixed_kernel<8, 8, 0>), grid, block, 0, s, a);
+    else if (D <= 8) PMN_LAUNCH(init_hypotheses_kernel<8>, grid, block, 0, s, a);
+    else if (D <= 16) PMN_LAUNCH(init_hypotheses_kernel<16>, grid, block, 0, s, a);
+    else if (D <= 32) PMN_LAUNCH(init_hypotheses_kernel<32>, grid, block, 0, s, a);
+    else PMN_LAUNCH(init_hypotheses_kernel<64>, grid, block, 0, s, a);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

@@ -36,7 +36,7 @@ extern "C" int pmn_nchw_to_nhwc(const float* in, float* out, int B, int C, int h
     if (!in || !out || B < 1 || C < 1 || h < 1 || w < 1) return PMN_ERR_ARG;
     if (C > 128) return PMN_ERR_SHAPE;
     const int hw = h * w;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((hw + 63) / 64, B), dim3(PMN_BLOCK), (size_t)C * 65 * sizeof(float),
+    PMN_LAUNCH(nchw_to_nhwc_kernel, dim3((hw + 63) / 64, B), dim3(PMN_BLOCK), (size_t)C * 65 * sizeof(float),
                        (hipStream_t)stream, in, out, C, hw);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -96,10 +96,10 @@ extern "C" int pmn_confidence(const float* score, int B, int D, int h, int w, in
                               int* depth_index_out, void* stream) {
     if (!score || !confidence_out || B < 1 || D < 1 || h < 1 || w < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
     if (H == 2 * h && W == 2 * w && (reinterpret_cast<uintptr_t>(confidence_out) & 7) == 0)
-        hipLaunchKernelGGL(confidence2x_kernel, dim3((h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+        PMN_LAUNCH(confidence2x_kernel, dim3((h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
                            (hipStream_t)stream, score, D, h, w, confidence_out, depth_index_out);
     else
-        hipLaunchKernelGGL(confidence_kernel, dim3((H * W + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+        PMN_LAUNCH(confidence_kernel, dim3((H * W + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
                            (hipStream_t)stream, score, D, h, w, H, W, confidence_out, depth_index_out);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -129,7 +129,7 @@ extern "C" int pmn_differentiable_warping(const float* src_nchw, const float* re
                                           int D, int h, int w, int hs, int ws, float* warped, void* stream) {
     if (!src_nchw || !rel_proj || !depth || !warped) return PMN_ERR_ARG;
     if (B < 1 || C < 1 || D < 1 || h < 2 || w < 2 || hs < 2 || ws < 2) return PMN_ERR_ARG;
-    hipLaunchKernelGGL(warping_kernel, dim3((D * h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
+    PMN_LAUNCH(warping_kernel, dim3((D * h * w + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0,
                        (hipStream_t)stream, src_nchw, rel_proj, depth, C, D, h, w, hs, ws, warped);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -232,8 +232,30 @@ extern "C" int pmn_stage_projections(const float* intrinsics, const float* extri
                                      float scale0, float* rel, void* stream) {
     if (!intrinsics || !extrinsics || !rel || B < 1 || V < 2 || nstages < 1) return PMN_ERR_ARG;
     const int total = nstages * B * (V - 1);
-    hipLaunchKernelGGL(stage_projections_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, intrinsics,
+    PMN_LAUNCH(stage_projections_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, intrinsics,
                        extrinsics, B, V, nstages, scale0, rel);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+// ---- Refinement's depth normalisation (reference models/net.py:104-106: (depth_0 - depth_min) / (depth_max - depth_min)) -----------
+// Two ATen kernels in round 5, and the only launches of a forward that did not come from this library: with them here a whole
+// forward is recordable as a launch plan (plan.hip).  Same operations as ATen's sub / sub / div on float32 tensors: IEEE
+// subtraction and correctly rounded division (hipcc's default for `/`), so the same bits.
+__global__ __launch_bounds__(PMN_BLOCK) void normalize_depth_kernel(const float* __restrict__ depth, const float* __restrict__ depth_min,
+                                                                    const float* __restrict__ depth_max, int n, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.y, i = blockIdx.x * PMN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float lo = depth_min[b], span = depth_max[b] - lo;
+    out[(size_t)b * n + i] = (depth[(size_t)b * n + i] - lo) / span;
+}
+
+extern "C" int pmn_normalize_depth(const float* depth, const float* depth_min, const float* depth_max, int B, int n, float* out,
+                                   void* stream) {
+    if (!depth || !depth_min || !depth_max || !out || B < 1 || n < 1) return PMN_ERR_ARG;
+    PMN_LAUNCH(normalize_depth_kernel, dim3((n + PMN_BLOCK - 1) / PMN_BLOCK, B), dim3(PMN_BLOCK), 0, (hipStream_t)stream, depth,
+               depth_min, depth_max, n, out);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }

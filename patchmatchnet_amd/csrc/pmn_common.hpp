@@ -219,8 +219,44 @@ __device__ __forceinline__ int pmn_xcd_tile(int bid, int ntiles) {
     return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
 }
 
+// ---- launches --------------------------------------------------------------------------------------------------------------
+// Every kernel of the library is launched through PMN_LAUNCH (same argument order as hipLaunchKernelGGL).  Normally that is one
+// hipLaunchKernel on the caller's stream.  While the calling THREAD records a launch plan (pmn_plan_begin .. pmn_plan_end, plan.hip)
+// nothing is launched: the kernel's host symbol, its grid and a copy of its arguments -- all passed by value, neighbour tables
+// included -- are appended to the plan, and pmn_plan_launch later replays the list with plain hipLaunchKernel calls from C: one
+// library call per forward instead of ~55 from Python, and no HIP graph (DESIGN_LESSONS.md lessons 45 and 46).
+#include <tuple>
+#include <utility>
+struct PmnPlan;
+extern thread_local PmnPlan* pmn_tls_plan;  // the plan this thread records into, or null (plan.hip)
+int pmn_plan_append(PmnPlan* plan, const void* func, dim3 grid, dim3 block, size_t lds, int nargs, void* const* args,
+                    const size_t* sizes, const size_t* aligns);
+
+template <typename... P, size_t... I>
+inline void pmn_launch_tuple(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::tuple<P...>& params,
+                             std::index_sequence<I...>) {
+    void* argv[] = {static_cast<void*>(&std::get<I>(params))...};
+    if (__builtin_expect(pmn_tls_plan != nullptr, 0)) {
+        const size_t sizes[] = {sizeof(P)...}, aligns[] = {alignof(P)...};
+        (void)pmn_plan_append(pmn_tls_plan, reinterpret_cast<const void*>(kernel), grid, block, lds, (int)sizeof...(P), argv, sizes,
+                              aligns);  // (a failed append poisons the plan: pmn_plan_end reports it)
+        return;
+    }
+    (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, stream);  // PMN_CHECK_LAUNCH reads the error
+}
+
+template <typename... P, typename... A>
+inline void pmn_launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A&&... args) {
+    static_assert(sizeof...(P) == sizeof...(A), "PMN_LAUNCH: argument count differs from the kernel's parameter list");
+    static_assert((std::is_trivially_copyable<P>::value && ...), "kernel parameters are copied bytewise into launch plans");
+    std::tuple<P...> params(std::forward<A>(args)...);
+    pmn_launch_tuple(kernel, grid, block, lds, stream, params, std::index_sequence_for<P...>{});
+}
+#define PMN_LAUNCH(kernel, ...) pmn_launch(kernel, __VA_ARGS__)
+
 #define PMN_CHECK_LAUNCH()                                  \
     do {                                                    \
+        if (pmn_tls_plan != nullptr) break; /* recording */ \
         hipError_t e_ = hipGetLastError();                  \
         if (e_ != hipSuccess) return PMN_ERR_LAUNCH;        \
     } while (0)

@@ -118,7 +118,7 @@ extern "C" int pmn_refine_front(const float* img, const float* t2, const float* 
                                 const float* sd, float* x16, int B, int H, int W, void* stream) {
     if (!img || !t2 || !w0 || !s0 || !wd || !sd || !x16 || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMN_ERR_ARG;
     const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(refine_front_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, t2, w0, s0, wd, sd, x16, B,
+    PMN_LAUNCH(refine_front_kernel, dim3(blocks), dim3(PMN_BLOCK), 0, (hipStream_t)stream, img, t2, w0, s0, wd, sd, x16, B,
                        H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -235,7 +235,7 @@ extern "C" int pmn_refine_tail(const float* x16, const float* w3, const float* s
     const size_t lds = (size_t)(20 * 424 + 18 * 256) * sizeof(float);  // 52.4 KB
     if (pmn_raise_dynamic_lds(reinterpret_cast<const void*>(refine_tail_kernel), lds) != PMN_OK) return PMN_ERR_LAUNCH;
     const int blocks = B * ((W + 15) / 16) * ((H + 15) / 16);
-    hipLaunchKernelGGL(refine_tail_kernel, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, x16, w3, s3, wr, dnorm,
+    PMN_LAUNCH(refine_tail_kernel, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, x16, w3, s3, wr, dnorm,
                        depth_min, depth_max, out, B, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;
@@ -514,10 +514,10 @@ extern "C" int pmn_refine_fused(const float* img, const float* t2, const float* 
     const void* kern = vec4 ? reinterpret_cast<const void*>(refine_fused_kernel<true>) : reinterpret_cast<const void*>(refine_fused_kernel<false>);
     if (pmn_raise_dynamic_lds(kern, lds) != PMN_OK) return PMN_ERR_LAUNCH;
     if (vec4)
-        hipLaunchKernelGGL(refine_fused_kernel<true>, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, img, t2, w0, s0, wd, sd,
+        PMN_LAUNCH(refine_fused_kernel<true>, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, img, t2, w0, s0, wd, sd,
                            reinterpret_cast<const f16x8*>(w3a), s3, wr, dnorm, depth_min, depth_max, out, B, H, W);
     else
-        hipLaunchKernelGGL(refine_fused_kernel<false>, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, img, t2, w0, s0, wd, sd,
+        PMN_LAUNCH(refine_fused_kernel<false>, dim3(blocks), dim3(PMN_BLOCK), lds, (hipStream_t)stream, img, t2, w0, s0, wd, sd,
                            reinterpret_cast<const f16x8*>(w3a), s3, wr, dnorm, depth_min, depth_max, out, B, H, W);
     PMN_CHECK_LAUNCH();
     return PMN_OK;

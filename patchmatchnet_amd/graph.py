@@ -41,17 +41,17 @@ class GraphedForward:
     samples) that is free; a pipeline that recycles its upload buffers keeps the default.  An image the kernel cannot read in place
     (not dense float32, or not 16-byte aligned) is copied into the slot and the table points there."""
 
-    _warned = False
-
-    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
+    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False, allow_several_hardware_queues: bool = False) -> None:
         import os
-        if os.environ.get("GPU_MAX_HW_QUEUES") != "1" and not GraphedForward._warned:
-            GraphedForward._warned = True
-            import warnings
-            warnings.warn("GraphedForward: GPU_MAX_HW_QUEUES is not 1 -- on this ROCm stack a forward replayed as a HIP graph while other "
-                          "work of the process runs on another hardware queue has been measured NOT to reproduce the eager forward bit for "
-                          "bit (DESIGN_LESSONS.md lesson 45); eval.py and bench.py set GPU_MAX_HW_QUEUES=1 before importing torch",
-                          RuntimeWarning, stacklevel=2)
+        if os.environ.get("GPU_MAX_HW_QUEUES") != "1" and not allow_several_hardware_queues and type(self) is GraphedForward:
+            # (round 5 only warned here; ADVICE r05: a warning keyed on the environment is not a guard.  It still is keyed on the
+            # environment -- HIP offers no query for the number of hardware queues it created -- so the product no longer uses this
+            # class at all: eval.py and bench.py replay launch plans, PlannedForward below, which need no such condition.)
+            raise PmnError("GraphedForward: GPU_MAX_HW_QUEUES is not 1 -- on this ROCm stack a forward replayed as a HIP graph while other "
+                           "work of the process runs on another hardware queue has been measured NOT to reproduce the eager forward bit "
+                           "for bit (DESIGN_LESSONS.md lessons 45-46).  Use PlannedForward (plain launches replayed from C, safe on any "
+                           "number of queues), or set GPU_MAX_HW_QUEUES=1 before the HIP runtime initialises, or pass "
+                           "allow_several_hardware_queues=True (probes only)")
         self.model, self.max_graphs, self.inputs_in_place = model, max_graphs, inputs_in_place
         self.cache: Dict[Tuple, Tuple] = {}
         self.replays = self.captures = self.evictions = 0
@@ -156,6 +156,14 @@ class GraphedForward:
 
         rng = torch.cuda.get_rng_state(dev)  # warm-up and capture must not advance the caller's random stream
         self._draw(static)
+        try:
+            handle, out = self._record(run, dev)
+        finally:
+            torch.cuda.set_rng_state(rng, dev)
+        return handle, static, out
+
+    def _record(self, run, dev):
+        """``run`` (the forward over the slot's static buffers) -> (replay handle, (depth, confidence) static outputs)."""
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # one eager pass off the capture: lazy kernel attributes, weight packing, allocator warm-up
@@ -166,8 +174,10 @@ class GraphedForward:
         # runtime (event waits, pinned allocations) while this thread captures
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             depth, confidence, _ = run()
-        torch.cuda.set_rng_state(rng, dev)
-        return graph, static, (depth, confidence)
+        return graph, (depth, confidence)
+
+    def _replay(self, handle, dev) -> None:
+        handle.replay()
 
     @staticmethod
     def _table_ok(features) -> bool:
@@ -274,6 +284,93 @@ class GraphedForward:
         graph, static, out = entry
         self._fill(static, images, intrinsics, extrinsics, depth_min, depth_max, features)
         self._draw(static)
-        graph.replay()
+        self._replay(graph, intrinsics.device)
         self.replays += 1
         return out
+
+
+class _LibraryLaunchesOnly(torch.utils._python_dispatch.TorchDispatchMode):
+    """Active while a forward is being recorded into a launch plan: every ATen operator the forward dispatches is checked.  Views and
+    allocations are fine -- they launch nothing --; anything else would run ONCE, now, on uninitialised inputs, and be absent from
+    every replay: a silently wrong plan.  So it raises, naming the operator."""
+
+    _ALLOC = ("aten.empty.", "aten.empty_strided.", "aten.empty_like.", "aten.new_empty.", "aten.new_empty_strided.", "aten.detach.",
+              "aten.alias.", "aten.lift_fresh.", "aten._unsafe_view.", "aten.reshape.", "aten.view.", "aten.sym_size.",
+              "aten.sym_stride.", "aten.sym_numel.", "aten.sym_storage_offset.", "aten.is_contiguous.", "aten.size.", "aten.stride.",
+              "aten.numel.", "aten.dim.", "aten.is_pinned.", "prim.device.", "prim.dtype.", "prim.layout.", "aten.record_stream.")
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if not (getattr(func, "is_view", False) or (str(func) + ".").startswith(self._ALLOC)):
+            raise PmnError(f"PlannedForward: the forward dispatched {func} while it was being recorded -- an operator outside "
+                           "libpmn_hip.so cannot be part of a launch plan (it would run once, on uninitialised data, and never "
+                           "again); this input signature has to run eagerly or through a path that only calls the library")
+        return func(*args, **(kwargs or {}))
+
+
+class PlannedForward(GraphedForward):
+    """GraphedForward's interface and static-buffer machinery, with the forward recorded as a LAUNCH PLAN (include/pmn_hip.h,
+    pmn_plan_*; csrc/plan.hip) instead of a HIP graph: the recording pass runs the forward once while the calling thread's entry points
+    append their launches to the plan instead of enqueuing them, and a replay is one pmn_plan_launch -- a C loop of plain
+    hipLaunchKernel calls on the current stream, ~55 per forward, no interpreter in between.
+
+    Why not the graph (DESIGN_LESSONS.md lessons 45-46): replayed HIP graphs that overlap other work of the process on another hardware
+    queue did not reproduce the eager forward on this ROCm stack; plain launches on several streams do.  A plan replay IS plain
+    launches, so several samples can be in flight on their own streams, on the runtime's default hardware queues, with the eager
+    forward's bits (tests/test_plan_gpu.py holds it to that without any environment override; bench.py verifies its timed mode).
+
+    What a plan needs from the forward: every launch comes from libpmn_hip.so (the recording pass raises on any other ATen operator,
+    see _LibraryLaunchesOnly) and every buffer it touches stays in place: the pass allocates from a private torch memory pool that
+    lives as long as the plan, exactly like a graph's private pool."""
+
+    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
+        super().__init__(model, max_graphs=max_graphs, inputs_in_place=inputs_in_place, allow_several_hardware_queues=True)
+
+    def _record(self, run, dev):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        run()  # one eager pass: lazy kernel attributes, weight packing (their ATen work must not fall into the recording pass)
+        with torch.cuda.device(dev):
+            pool = torch.cuda.MemPool()
+            plan = ctypes.c_void_p()
+            _lib.check(L.pmn_plan_create(ctypes.byref(plan)), "pmn_plan_create")
+            handle = _Plan(plan, pool)
+            with torch.cuda.use_mem_pool(pool, device=dev):
+                _lib.check(L.pmn_plan_begin(plan), "pmn_plan_begin")
+                try:
+                    with _LibraryLaunchesOnly():
+                        depth, confidence, _ = run()
+                finally:
+                    rc = L.pmn_plan_end(plan)
+                _lib.check(rc, "pmn_plan_end")
+        handle.count = L.pmn_plan_count(plan)
+        if handle.count <= 0:
+            raise PmnError("PlannedForward: the recording pass recorded no launch")
+        # (the recording pass launched nothing: depth / confidence are uninitialised until the first replay, which __call__ issues
+        # right after a capture)
+        return handle, (depth, confidence)
+
+    def _replay(self, handle, dev) -> None:
+        from . import _lib
+        _lib.check(_lib.lib().pmn_plan_launch(handle.plan, torch.cuda.current_stream(dev).cuda_stream), "pmn_plan_launch")
+
+
+class _Plan:
+    """Owns one pmn_plan and the torch memory pool its recorded addresses live in."""
+
+    def __init__(self, plan, pool) -> None:
+        self.plan, self.pool, self.count = plan, pool, 0
+
+    def kernel_names(self) -> List[str]:
+        from . import _lib
+        L = _lib.lib()
+        return [(L.pmn_plan_kernel_name(self.plan, i) or b"?").decode() for i in range(self.count)]
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self.plan:
+                _lib.lib().pmn_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass

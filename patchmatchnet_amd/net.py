@@ -248,9 +248,12 @@ class Refinement(nn.Module):
         """Same computation through pmn_conv2d / pmn_deconv3x3s2 (channels-last, BatchNorm + ReLU fused)."""
         pk = self._packed()
         b = depth_min.size()[0]
-        lo = depth_min.view(b, 1, 1, 1)
-        span = (depth_max - depth_min).view(b, 1, 1, 1)
-        d = ((depth_0 - lo) / span).contiguous()
+        if not self.research["layers"]:
+            d = ops.normalize_depth(depth_0, depth_min, depth_max)  # (depth_0 - lo) / span, same bits, a launch of the library
+        else:
+            lo = depth_min.view(b, 1, 1, 1)
+            span = (depth_max - depth_min).view(b, 1, 1, 1)
+            d = ((depth_0 - lo) / span).contiguous()
         t = ops.conv2d(d, *pk["conv1"], 8, 3, 1, 1, relu=True, in_nchw=True)                             # [B,H/2,W/2,8]
         t = ops.conv2d(t, *pk["conv2"], 8, 3, 1, 1, relu=True)
         if not self.research["layers"]:

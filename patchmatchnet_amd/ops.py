@@ -401,6 +401,21 @@ def stage_projections(intrinsics: torch.Tensor, extrinsics: torch.Tensor, nstage
     return rel
 
 
+def normalize_depth(depth: torch.Tensor, depth_min: torch.Tensor, depth_max: torch.Tensor) -> torch.Tensor:
+    """pmn_normalize_depth: (depth - depth_min[b]) / (depth_max[b] - depth_min[b]) for depth [B, ...] (reference models/net.py:104-106),
+    the bits of the torch expression; with it the forward launches nothing but this library's kernels (launch plans, plan.py)."""
+    depth = _dev(depth.contiguous(), "depth")
+    lo, hi = _dev(depth_min.float().contiguous(), "depth_min"), _dev(depth_max.float().contiguous(), "depth_max")
+    B = depth.shape[0]
+    if lo.numel() != B or hi.numel() != B:
+        raise PmnError("normalize_depth: depth_min / depth_max must hold one value per batch element")
+    out = torch.empty_like(depth)
+    with torch.cuda.device(depth.device):
+        check(_lib.lib().pmn_normalize_depth(depth.data_ptr(), lo.data_ptr(), hi.data_ptr(), B, depth.numel() // B, out.data_ptr(),
+                                             _stream(out)), "pmn_normalize_depth")
+    return out
+
+
 def conv2d(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, K: int, stride: int = 1, pad: int = 0,
            dil: int = 1, relu: bool = False, up: Optional[torch.Tensor] = None, in_nchw: bool = False,
            out_nchw: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -1,6 +1,6 @@
 """GPU tests of the measurement contract: bench.py prints ONE JSON line with the agreed keys, in the default mode (three samples
-in flight, HIP-graph replay), in the eager mode, and with two ranks (control flow of the multi-GPU launch: the collective
-decision about graph capture, the closing all-gather, max over ranks) -- the two ranks share cuda:0 over gloo, which is what this
+in flight, launch-plan replay), in the eager mode, and with two ranks (control flow of the multi-GPU launch: the collective
+decision about the recording, the closing all-gather, max over ranks) -- the two ranks share cuda:0 over gloo, which is what this
 box allows; on a multi-GPU node the same code runs over RCCL."""
 import json
 import os
@@ -48,14 +48,28 @@ def test_bench_line_default_and_eager():
         line = _line(p.stdout)
         _check(line, 1)
         assert line["config"]["in_flight"] == (1 if extra else 3)
-        # the timed mode's outputs are the eager forward's, bit for bit (one hardware queue: bench.py sets it for itself)
-        assert line["config"]["hardware_queues"] == "1"
+        # the timed mode's outputs are the eager forward's, bit for bit, on the runtime's default hardware queues
+        assert "default" in line["config"]["hardware_queues"], line["config"]["hardware_queues"]
         ver = line["outputs_verified"]
         assert (ver is None) == bool(extra) and (extra or (ver["steps"] >= 6 and ver["steps_that_differ_from_the_eager_forward"] == 0)), ver
-        # both input modes of the graph replay are on the line (in place = `value`; copied into the slot = rounds 2-4's `value`)
+        # both input modes of the replay are on the line (in place = `value`; copied into the slot = rounds 2-4's `value`)
         other = line["value_other_input_mode"]
         assert (other is None) == bool(extra) and (extra or (other["value"] > 0 and "copied" in other["mode"]))
-        assert ("graph" in line["config"]["launch"]) == (not extra), line["config"]["launch"]
+        assert ("launch-plan replay" in line["config"]["launch"]) == (not extra), line["config"]["launch"]
+        assert line["warmup"] == line["config"]["untimed_steps_before_the_timed_region"] >= line["warmup_requested"] == 2
+
+
+def test_bench_graph_mode_runs_on_one_hardware_queue():
+    """--launch graph = round 5's mode: HIP-graph replay, for which bench.py sets GPU_MAX_HW_QUEUES=1 before torch initialises HIP."""
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--launch", "graph"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _line(p.stdout)
+    _check(line, 1)
+    assert line["config"]["hardware_queues"] == "1" and "HIP-graph replay" in line["config"]["launch"]
+    assert line["outputs_verified"]["steps_that_differ_from_the_eager_forward"] == 0
 
 
 def test_bench_two_ranks_on_one_gpu():
