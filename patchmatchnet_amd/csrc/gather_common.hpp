@@ -35,6 +35,38 @@ __device__ __forceinline__ float pmn_pair_swap(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
+// ---- lesson 46: packed fp32 math must not read what an LDS load has just written ---------------------------------------------------
+// Measured on MI355X (profiles/r06_overlap/, scripts/overlap_pairs.py, DESIGN_LESSONS.md lesson 46): a v_pk_mul_f32 / v_pk_fma_f32
+// whose source registers were written by a ds_read a few cycles earlier can read their PREVIOUS contents -- for one 16-lane quarter
+// of the wave -- while waves of another kernel on the same CU issue back-to-back v_mfma_f32_16x16x32_f16 (this library's fp16-split
+// convolutions).  Alone, or beside any other kernel, the same code is bit-reproducible, which is why three rounds of single-stream
+// parity tests never saw it and why overlapped forwards differed from the eager forward in "a few thousand pixels' fifth digit"
+// (the stale operand is the previous item's tap weight or similarity: a plausible number).  Plain VALU reads of the same registers are
+// not affected, and neither are packed reads of VMEM-loaded or VALU-written registers.  So every value that goes from LDS into packed
+// math passes through ONE VALU move first: the move reads the LDS-written register safely, the packed instruction reads the move's
+// result.  Same bits, one v_mov per value.  -DPMN_NO_SETTLE restores the direct path (probe builds).
+__device__ __forceinline__ float pmn_settle(float v) {
+#ifndef PMN_NO_SETTLE
+    asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ float4 pmn_settle4(float4 v) {
+    return make_float4(pmn_settle(v.x), pmn_settle(v.y), pmn_settle(v.z), pmn_settle(v.w));
+}
+// probe switches (scripts/build_waitcnt_variants.sh): the PixelwiseNet inputs / the MLP's tail constants separately
+#ifndef PMN_SETTLE_X
+#define PMN_SETTLE_X 1
+#endif
+#ifndef PMN_SETTLE_TAIL
+#define PMN_SETTLE_TAIL 1
+#endif
+#ifndef PMN_SETTLE_W
+#define PMN_SETTLE_W 0
+#endif
+__device__ __forceinline__ float pmn_settle_x(float v) { return PMN_SETTLE_X ? pmn_settle(v) : v; }
+__device__ __forceinline__ float pmn_settle_t(float v) { return PMN_SETTLE_TAIL ? pmn_settle(v) : v; }
+
 // Pointwise MLP G -> 16 -> 8 -> 1 for NI items at once, weights read from LDS (uniform address = broadcast read).
 // Layers 1 and 2 are fused in a ROLLED loop over the 16 hidden units: unit j of every item is produced from weight row
 // j and immediately scattered into the 8 layer-2 accumulators with column j of the second weight matrix, so no array
@@ -116,7 +148,15 @@ __device__ __forceinline__ void mlp_pairs_from_lds(const float* __restrict__ W, 
             w1c[0] = c0.x; w1c[1] = c0.y; w1c[2] = c0.z; w1c[3] = c0.w;
             w1c[4] = c1.x; w1c[5] = c1.y; w1c[6] = c1.z; w1c[7] = c1.w;
         }
-        const float t0 = W[20 * j + 16];
+        float t0 = W[20 * j + 16];
+#if PMN_SETTLE_W  // the weight rows of the rolled loop (never caught failing, unlike the tail constants below: see lesson 46)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < G) w0[g] = pmn_settle(w0[g]);
+            w1c[g] = pmn_settle(w1c[g]);
+        }
+        t0 = pmn_settle(t0);
+#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             pmn_f2 acc = pmn_f2{w0[0], w0[0]} * x[p][0];
@@ -131,9 +171,12 @@ __device__ __forceinline__ void mlp_pairs_from_lds(const float* __restrict__ W, 
     }
     const float4 ta = reinterpret_cast<const float4*>(W + 320)[0], tb = reinterpret_cast<const float4*>(W + 320)[1];
     const float4 wa = reinterpret_cast<const float4*>(W + 328)[0], wb = reinterpret_cast<const float4*>(W + 328)[1];
-    const float t1[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-    const float w2[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    const float b2 = W[336];
+    // (read from LDS and used by packed instructions right away: lesson 46)
+    const float t1[8] = {pmn_settle_t(ta.x), pmn_settle_t(ta.y), pmn_settle_t(ta.z), pmn_settle_t(ta.w), pmn_settle_t(tb.x), pmn_settle_t(tb.y),
+                         pmn_settle_t(tb.z), pmn_settle_t(tb.w)};
+    const float w2[8] = {pmn_settle_t(wa.x), pmn_settle_t(wa.y), pmn_settle_t(wa.z), pmn_settle_t(wa.w), pmn_settle_t(wb.x), pmn_settle_t(wb.y),
+                         pmn_settle_t(wb.z), pmn_settle_t(wb.w)};
+    const float b2 = pmn_settle_t(W[336]);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         pmn_f2 h = a1[p][0] + pmn_f2{t1[0], t1[0]};

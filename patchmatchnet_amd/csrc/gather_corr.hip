@@ -129,8 +129,6 @@ __device__ __forceinline__ float blend_corners(const PmnCorners& c, float4 w4, c
         if (LPG == 2) s += pmn_pair_swap(s);
         return s * (1.0f / CG);
     }
-#elif defined(PMN_DBG_BLEND) && PMN_DBG_BLEND == 2  // ... packed math, the weights passed through a VALU move first
-    asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
 #endif
     const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
     pmn_f2 lo = pmn_f2{c.t00.x, c.t00.y} * wa;
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
 #pragma unroll
                 for (int i = 0; i < NBP; ++i) {
                     const int r = (d + i - dc0) * NPIX;
-                    wq[i] = rw[r];
+                    wq[i] = pmn_settle4(rw[r]);  // LDS -> packed math (blend_corners): lesson 46
 #if defined(PMN_DBG_LANE) && PMN_DBG_LANE == 4  // lesson 46 probe: taps that do not come from the LDS records
                     wq[i] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
                     cn[i] = load_corners<C>(sbase, (unsigned)(min(yB, hs - 2) * ws + min(xB + d + i, ws - 2)) * (C * 4) + lane_bytes, row_bytes);
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
                 __builtin_amdgcn_sched_barrier(0);
             }
             for (; d < dc1; ++d) {
-                const float s = gather_item<LPI, LPG, CG>(srcv, rw[(d - dc0) * NPIX], ro[(d - dc0) * NPIX], ws, refq);
+                const float s = gather_item<LPI, LPG, CG>(srcv, pmn_settle4(rw[(d - dc0) * NPIX]), ro[(d - dc0) * NPIX], ws, refq);
                 if (owner) simt[gB * SS + d * NPIX + grp] = s;
             }
             __syncthreads();
@@ -527,7 +525,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
                     for (int i = 0; i < NV; ++i) {
                         const int d = min(dA0 + (c * NI + i) * DSTEP, D - 1);
 #pragma unroll
-                        for (int g = 0; g < G; ++g) xc[i][g] = simt[g * SS + d * NPIX + pixA];
+                        for (int g = 0; g < G; ++g) xc[i][g] = pmn_settle(simt[g * SS + d * NPIX + pixA]);  // (hipcc may pack the MLP's fmas: lesson 46)
                     }
                     mlp_from_lds<G, NV>(wlds_a, xc, oc);
 #pragma unroll
@@ -569,7 +567,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
                 {
                     const int da = min(dA0 + (c * NI) * DSTEP, D - 1), db = min(dA0 + (c * NI + 1) * DSTEP, D - 1);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) xq[0][g] = pmn_f2{simt[g * SS + da * NPIX + pixA], simt[g * SS + db * NPIX + pixA]};
+                    for (int g = 0; g < G; ++g) xq[0][g] = pmn_f2{pmn_settle(simt[g * SS + da * NPIX + pixA]), pmn_settle(simt[g * SS + db * NPIX + pixA])};
                 }
                 mlp_pairs_from_lds<G, 1>(wlds_b, xq, rq);
                 r[0] = rq[0].x;
@@ -593,7 +591,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
         for (int j = 0; j < NIT; ++j) {
             const int d = min(dA0 + j * DSTEP, D - 1);
 #pragma unroll
-            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], simt[g * SS + d * NPIX + pixA], vwp);
+            for (int g = 0; g < G; ++g) ssum[j][g] = mul_add_unfused(ssum[j][g], pmn_settle(simt[g * SS + d * NPIX + pixA]), vwp);
         }
         wsum += vwp;
         if (tid < NPIX && okA) {
@@ -812,6 +810,10 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
                 const float2 t2 = *reinterpret_cast<const float2*>(xrow + g * GS);
                 x[0][g] = t2.x; x[1][g] = t2.y;
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {  // LDS -> packed MLP: lesson 46 (a second loop: all eight reads in flight, then the moves)
+                x[0][g] = pmn_settle_x(x[0][g]); x[1][g] = pmn_settle_x(x[1][g]);
+            }
         }
         unsigned long long best = 0ull;
 #pragma unroll
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
                     xq[0][g] = pmn_f2{x[0][g], x[1][g]};
                 } else {
                     const float2 t2 = *reinterpret_cast<const float2*>(xrow + g * GS + 2 * c);
-                    xq[0][g] = pmn_f2{t2.x, t2.y};
+                    xq[0][g] = pmn_f2{pmn_settle(t2.x), pmn_settle(t2.y)};
                 }
             }
             mlp_pairs_from_lds<G, 1>(wlds_b, xq, rq);
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
         if constexpr (NIT == 4) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float4 t4 = *reinterpret_cast<const float4*>(xrow + g * GS);
+                const float4 t4 = pmn_settle4(*reinterpret_cast<const float4*>(xrow + g * GS));
                 x[0][g] = t4.x; x[1][g] = t4.y; x[2][g] = t4.z; x[3][g] = t4.w;
             }
         }

@@ -16,6 +16,5 @@ build() { # name opt flags...
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/wc/libpmn_hip_$name.so build/wc/gather_corr_$name.o $OTHERS
   echo "built build/wc/libpmn_hip_$name.so"
 }
-build dbg9 -O3 -DPMN_DBG_NEIGHBOR=1 -DPMN_DBG_BLEND=1 &
-build dbg10 -O3 -DPMN_DBG_NEIGHBOR=1 -DPMN_DBG_BLEND=2 &
+build rows -O3 -DPMN_SETTLE_W=1 &
 wait

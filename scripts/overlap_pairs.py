@@ -166,6 +166,16 @@ with torch.no_grad():
             torch.cuda.synchronize()
             for o in outs:
                 o = o if isinstance(o, (tuple, list)) else (o,)
+                if len(o) >= 2 and vwant[1] is not None and o[0].dim() == 4 and o[1].dim() == 4 and not torch.equal(o[0], vwant[0]):
+                    # warp_correlate: pixels whose cost differs vs pixels where some view weight differs
+                    pc = (o[0] != vwant[0]).any(1)[0]
+                    pv = (o[1] != vwant[1]).any(1)[0]
+                    print(f"trial {trial}: pixels with a different cost {int(pc.sum())}, with a different view weight {int(pv.sum())}, "
+                          f"cost differs but no view weight does {int((pc & ~pv).sum())}, per-view counts "
+                          f"{[int((o[1][0, v] != vwant[1][0, v]).sum()) for v in range(o[1].shape[1])]}")
+                    dv = (o[1] - vwant[1])[o[1] != vwant[1]]
+                    print(f"trial {trial}: view-weight differences: {int((dv < 0).sum())} lower, {int((dv > 0).sum())} higher; "
+                          f"first few got/want {[(round(float(a), 6), round(float(b), 6)) for a, b in zip(o[1][o[1] != vwant[1]][:8], vwant[1][o[1] != vwant[1]][:8])]}")
                 for j, (g, w_) in enumerate(zip(o, vwant)):
                     if w_ is None or torch.equal(g, w_):
                         continue
