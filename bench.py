@@ -13,12 +13,12 @@ confidence maps closes the timed region, as the per-scan gather before fusion do
 
 Timed region (``value``): every forward is issued as ONE launch-plan replay (patchmatchnet_amd/graph.py: PlannedForward; the forward's
 ~55 launches recorded once and replayed from C with plain hipLaunchKernel calls, include/pmn_hip.h pmn_plan_*), --in-flight S replay
-slots (default three) on their own HIP streams, on the runtime's default hardware queues, so that forwards of different samples overlap
-on the device.  Rounds 2-5 replayed HIP graphs instead: overlapping graph replays do not reproduce the eager forward on this ROCm stack
-(DESIGN_LESSONS.md lessons 45-46), plain launches do.  ``--launch graph`` keeps the round-5 mode (HIP-graph replay, ONE hardware
-queue: GPU_MAX_HW_QUEUES=1 is then set below before torch initialises HIP).  ``outputs_verified`` on the line: --verify-steps further
+slots on their own HIP streams, on the runtime's default hardware queues, so that forwards of different samples overlap on the device.
+``--launch graph`` replays HIP graphs instead (rounds 2-5's form; same rate).  ``outputs_verified`` on the line: --verify-steps further
 steps in exactly the timed mode, compared BIT FOR BIT with the same steps launched eagerly one at a time; a mismatch makes the
-process exit non-zero.
+process exit non-zero.  (Rounds 2-4 overlapped forwards whose outputs were NOT the eager forward's, round 5 found that out and fell
+back to one hardware queue; round 6 found the cause -- two kernels of this library compute wrong values beside kernels that issue
+dense fp16 MFMAs, DESIGN_LESSONS.md lesson 46 -- and fixed it: overlap is back, verified.)
 ``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
 (``single_stream_eager`` = one sample's latency).
 
@@ -46,12 +46,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# --launch graph (round 5's mode) needs ONE hardware queue for the process: a forward replayed as a HIP graph while any other work of
-# the process runs on another hardware queue came out different from the eager forward (DESIGN_LESSONS.md lesson 45).  HIP reads the
-# variable when the runtime initialises, i.e. before torch is imported, hence the look at argv here.  The default mode (launch plans:
-# plain launches) runs on whatever the runtime creates.
-if "graph" in [a.split("=")[-1] for i, a in enumerate(sys.argv) if a.startswith("--launch=") or (i and sys.argv[i - 1] == "--launch")]:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -332,8 +326,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="independent samples in flight per GPU: one HIP stream + one replay slot each (1 = one stream)")
     ap.add_argument("--launch", choices=("plan", "graph"), default="plan",
-                    help="plan = the forward recorded as a launch plan and replayed from C with plain launches (default); graph = round "
-                         "5's HIP-graph replay on one hardware queue")
+                    help="plan = the forward recorded as a launch plan and replayed from C with plain launches (default); graph = "
+                         "HIP-graph replay (rounds 2-5)")
     ap.add_argument("--copy-inputs", action="store_true",
                     help="graph replay reads copies of all six images in the slot's static buffers (rounds 2-4) instead of the samples in place")
     ap.add_argument("--eager", action="store_true",
@@ -550,10 +544,10 @@ def main():
             steady = (n_steady, reduce_scalar(region["run"](n_steady), dist.ReduceOp.MAX))
 
 
-        # ---- are the outputs of the timed MODE right?  V steps exactly as in the timed region (S samples in flight, graph replay), every
+        # ---- are the outputs of the timed MODE right?  V steps exactly as in the timed region (S samples in flight, replayed), every
         # step's stage-3 draw seeded, every step's (depth, confidence) kept; then the same steps one at a time, eagerly, under the same
-        # seeds: the two must agree BIT FOR BIT (round 5: forwards replayed concurrently had come out a few pixels -- now and then
-        # entirely -- wrong: a kernel with a scratch frame inside concurrently replayed HIP graphs, DESIGN_LESSONS.md lesson 45)
+        # seeds: the two must agree BIT FOR BIT (rounds 2-5: overlapped forwards had come out a few pixels -- now and then entirely --
+        # wrong: DESIGN_LESSONS.md lessons 45-46)
         verified = None
         if not args.eager and launch_note is None and args.verify_steps > 0 and "replay" in region:
             V = args.verify_steps

@@ -23,12 +23,6 @@ import queue
 import sys
 import time
 
-# --hip_graph 2 (round 5's HIP-graph replay) needs ONE hardware queue for the process: a forward replayed as a HIP graph while any other
-# work of the process runs on another hardware queue came out different from the eager forward (DESIGN_LESSONS.md lesson 45).  HIP reads
-# the variable when the runtime initialises, i.e. before torch is imported, hence the look at argv here.  The default (--hip_graph 1 =
-# launch plans: plain launches replayed from C) runs on whatever queues the runtime creates.
-if any(a == "--hip_graph=2" or (i and sys.argv[i - 1] == "--hip_graph" and a == "2") for i, a in enumerate(sys.argv)):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
 import numpy as np
 import torch
 from torch.utils.data import DataLoader
@@ -380,7 +374,7 @@ def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
     # instead of ~55 Python-issued launches -- the launch thread is what the uploads and the writer threads compete with;
     # --in_flight S: S samples in flight, each on its own HIP stream with its own replay slot, so that the gathers of one sample
     # (vector-memory pipe) share the CUs with the convolutions of the other (matrix cores).  Same maps bit for bit
-    # (patchmatchnet_amd/graph.py, tests/test_eval_gpu.py).  --hip_graph 2: round 5's HIP-graph replay (one hardware queue).
+    # (patchmatchnet_amd/graph.py, tests/test_eval_gpu.py).  --hip_graph 2: HIP-graph replay instead (rounds 2-5's form).
     main_stream = torch.cuda.current_stream(device)
     n_slots = max(args.in_flight, 1) if args.hip_graph else 1
     streams = [torch.cuda.Stream(device) for _ in range(n_slots)] if args.hip_graph else [main_stream]
@@ -904,8 +898,7 @@ def build_parser():
                    help="samples in flight per GPU (HIP streams, one replay slot each); needs --hip_graph 1 or 2")
     p.add_argument("--hip_graph", type=int, default=1, choices=(0, 1, 2),
                    help="1: replay the forward as a launch plan (one library call per sample: its launches recorded once, re-issued "
-                        "from C with plain hipLaunchKernel calls); 2: round 5's HIP-graph replay (sets GPU_MAX_HW_QUEUES=1: overlapping "
-                        "graph replays are not bit-exact on several hardware queues); 0: issue every kernel from Python")
+                        "from C with plain hipLaunchKernel calls); 2: HIP-graph replay; 0: issue every kernel from Python")
     p.add_argument("--stream_views", type=int, default=1,
                    help="1: with --feature_cache, decode every view once through ONE DataLoader over all scans, in first-use order, "
                         "overlapped with the forwards; 0: two passes per scan (decode + encode all views, then the samples)")

@@ -304,9 +304,7 @@ int pmn_normalize_depth(const float *depth, const float *depth_min, const float 
 /* ---- ABI 20: launch plans -------------------------------------------------------------------------------------------------------
  * A plan is a recorded list of kernel launches that pmn_plan_launch replays on a stream with plain hipLaunchKernel calls from C: the
  * whole forward (reference models/net.py:176-301, the body of the loop at eval.py:56-65) as ONE library call per sample, without a
- * HIP graph.  (Rounds 2-5 replayed a captured HIP graph; on this ROCm stack a graph replay that overlaps other work of the process
- * on another hardware queue does not reproduce the eager forward bit for bit, plain launches on several streams do:
- * DESIGN_LESSONS.md lessons 45-46.)
+ * HIP graph (same replay rate; nothing but kernel launches to depend on; the plan's contents can be listed).
  *
  *   pmn_plan_create(&plan)
  *   pmn_plan_begin(plan)          from now on every pmn_* entry point called BY THIS THREAD validates its arguments as usual but

@@ -1,11 +1,11 @@
 // Launch plans: a forward recorded once, replayed from C with plain kernel launches (include/pmn_hip.h: pmn_plan_*).
 //
-// Why this exists (DESIGN_LESSONS.md lessons 45-46).  One PatchmatchNet forward is ~55 kernel launches.  Issued from Python they cost
-// about as much interpreter time as the kernels take to run, so rounds 2-5 captured the forward into a HIP graph and replayed that.
-// On this ROCm stack a forward replayed as a HIP GRAPH while other work of the process runs on another hardware queue does not
-// reproduce the eager forward bit for bit, whereas the same kernels launched one by one on several streams do (300 of 300).  A plan
-// keeps what the graph bought -- one call per forward, no interpreter between the launches -- and drops the graph: pmn_plan_launch is
-// a loop of hipLaunchKernel calls on the caller's stream, exactly what the entry points themselves do.
+// Why this exists.  One PatchmatchNet forward is ~55 kernel launches.  Issued from Python they cost about as much interpreter time as
+// the kernels take to run, which is what stops several samples from being in flight; rounds 2-5 captured the forward into a HIP graph
+// and replayed that.  A plan keeps what the graph bought -- one call per forward, no interpreter between the launches -- without the
+// graph: pmn_plan_launch is a loop of hipLaunchKernel calls on the caller's stream, exactly what the entry points themselves do, so it
+// depends on nothing but kernel launches (no capture modes, no graph memory pools, no runtime-version-specific replay path) and its
+// contents can be listed.  Same replay rate as the graph (bench.py --launch graph | plan).
 //
 // Recording is per THREAD: between pmn_plan_begin and pmn_plan_end every PMN_LAUNCH of the calling thread (pmn_common.hpp) appends
 // {kernel symbol, grid, block, dynamic LDS, argument bytes} to the plan instead of launching; other threads keep launching.  Kernel

@@ -224,7 +224,7 @@ __device__ __forceinline__ int pmn_xcd_tile(int bid, int ntiles) {
 // hipLaunchKernel on the caller's stream.  While the calling THREAD records a launch plan (pmn_plan_begin .. pmn_plan_end, plan.hip)
 // nothing is launched: the kernel's host symbol, its grid and a copy of its arguments -- all passed by value, neighbour tables
 // included -- are appended to the plan, and pmn_plan_launch later replays the list with plain hipLaunchKernel calls from C: one
-// library call per forward instead of ~55 from Python, and no HIP graph (DESIGN_LESSONS.md lessons 45 and 46).
+// library call per forward instead of ~55 from Python, and no HIP graph.
 #include <tuple>
 #include <utility>
 struct PmnPlan;

@@ -41,17 +41,7 @@ class GraphedForward:
     samples) that is free; a pipeline that recycles its upload buffers keeps the default.  An image the kernel cannot read in place
     (not dense float32, or not 16-byte aligned) is copied into the slot and the table points there."""
 
-    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False, allow_several_hardware_queues: bool = False) -> None:
-        import os
-        if os.environ.get("GPU_MAX_HW_QUEUES") != "1" and not allow_several_hardware_queues and type(self) is GraphedForward:
-            # (round 5 only warned here; ADVICE r05: a warning keyed on the environment is not a guard.  It still is keyed on the
-            # environment -- HIP offers no query for the number of hardware queues it created -- so the product no longer uses this
-            # class at all: eval.py and bench.py replay launch plans, PlannedForward below, which need no such condition.)
-            raise PmnError("GraphedForward: GPU_MAX_HW_QUEUES is not 1 -- on this ROCm stack a forward replayed as a HIP graph while other "
-                           "work of the process runs on another hardware queue has been measured NOT to reproduce the eager forward bit "
-                           "for bit (DESIGN_LESSONS.md lessons 45-46).  Use PlannedForward (plain launches replayed from C, safe on any "
-                           "number of queues), or set GPU_MAX_HW_QUEUES=1 before the HIP runtime initialises, or pass "
-                           "allow_several_hardware_queues=True (probes only)")
+    def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
         self.model, self.max_graphs, self.inputs_in_place = model, max_graphs, inputs_in_place
         self.cache: Dict[Tuple, Tuple] = {}
         self.replays = self.captures = self.evictions = 0
@@ -313,17 +303,19 @@ class PlannedForward(GraphedForward):
     append their launches to the plan instead of enqueuing them, and a replay is one pmn_plan_launch -- a C loop of plain
     hipLaunchKernel calls on the current stream, ~55 per forward, no interpreter in between.
 
-    Why not the graph (DESIGN_LESSONS.md lessons 45-46): replayed HIP graphs that overlap other work of the process on another hardware
-    queue did not reproduce the eager forward on this ROCm stack; plain launches on several streams do.  A plan replay IS plain
-    launches, so several samples can be in flight on their own streams, on the runtime's default hardware queues, with the eager
-    forward's bits (tests/test_plan_gpu.py holds it to that without any environment override; bench.py verifies its timed mode).
+    Why a plan and not the graph: a plan is a page of C (csrc/plan.hip) instead of a runtime feature -- no capture mode, no private
+    graph memory pools inside the runtime, no dependence on how a ROCm release replays graphs --, its replay rate is the graph's
+    (bench.py --launch graph vs plan: 373-377 vs 376-384 depth-maps/s, round 6) and its contents can be listed (kernel_names()).
+    (Round 5 blamed HIP-graph replay for overlapped forwards that differed from the eager forward; round 6 found the cause in two of
+    this library's own kernels -- DESIGN_LESSONS.md lesson 46 -- and both replay forms are bit-exact on any number of hardware queues
+    since: tests/test_plan_gpu.py, tests/test_overlap_gpu.py, bench.py's outputs_verified.)
 
     What a plan needs from the forward: every launch comes from libpmn_hip.so (the recording pass raises on any other ATen operator,
     see _LibraryLaunchesOnly) and every buffer it touches stays in place: the pass allocates from a private torch memory pool that
     lives as long as the plan, exactly like a graph's private pool."""
 
     def __init__(self, model, max_graphs: int = 8, inputs_in_place: bool = False) -> None:
-        super().__init__(model, max_graphs=max_graphs, inputs_in_place=inputs_in_place, allow_several_hardware_queues=True)
+        super().__init__(model, max_graphs=max_graphs, inputs_in_place=inputs_in_place)
 
     def _record(self, run, dev):
         import ctypes

@@ -3,10 +3,8 @@ import sys
 
 import pytest
 
-# No GPU_MAX_HW_QUEUES override here (round 5 set it to 1 for the whole suite, which hid the very failure it was about): the product
-# replays launch plans (plain launches, patchmatchnet_amd/graph.py: PlannedForward), which must be bit-identical to the eager forward
-# on the runtime's default hardware queues, and the suite runs on those.  The one test of the round-5 HIP-graph mode runs in a child
-# process with its own environment (tests/test_plan_gpu.py).
+# No GPU_MAX_HW_QUEUES override here (round 5 set it to 1 for the whole suite, which hid the very failure it was about): replayed
+# forwards must be bit-identical to the eager forward on the runtime's default hardware queues, and the suite runs on those.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):

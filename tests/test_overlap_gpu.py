@@ -1,0 +1,90 @@
+"""GPU test for DESIGN_LESSONS.md lesson 46: every kernel launch of a forward must compute the same bits whether it has the device to
+itself or runs beside the kernels that were measured to disturb it.
+
+What round 6 found: while waves of another kernel issue back-to-back v_mfma_f32_16x16x32_f16 on the same CU (this library's fp16-split
+convolutions: pmn_conv2d_f16s, pmn_stem_f16s, pmn_offset_heads_f16s, pmn_refine_fused), a v_pk_*_f32 instruction could read the
+PREVIOUS contents of a register an LDS load had written -- in the three FeatureWeightNet launches (the tap weights) and in the
+PixelwiseNet launch (the MLP's tail constants): 24 of 24 disturbed launches wrong, a few hundred pixels each, which is what made
+overlapped forwards differ from the eager forward for four rounds.  Single-stream parity tests cannot see this class of defect, so
+this test re-issues every captured ops.* call of one forward on stream A while stream B loops the two strongest disturbers, and
+compares with the call's solo output, bit for bit."""
+import pytest
+import torch
+
+import goldenutil as GU
+import synth
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["stem_f16s", "conv2d_f16s", "pointwise_split_mfma", "fpn_level", "stage_projections", "offset_heads_f16s", "feature_weight",
+         "init_hypotheses", "warp_correlate", "aggregate_regress", "normalize_depth", "conv2d", "refine_fused", "confidence"]
+
+
+def _capture_forward(H, W, n_src):
+    import patchmatchnet_amd as P
+    from patchmatchnet_amd import ops
+    _, params, kw = GU.load_case("default")
+    model = P.PatchmatchNet(**kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.cuda().eval()
+    imgs, intr, extr, _ = synth.render_scene(n_src + 1, H, W, seed=5, device="cuda")
+    imgs = [im.cuda().contiguous() for im in imgs]
+    orig = {n: getattr(ops, n) for n in NAMES}
+    calls = []
+
+    def wrap(name):
+        def g(*a, **kw_):
+            out = orig[name](*a, **kw_)
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            calls.append((name, a, {k: v for k, v in kw_.items() if k != "out"},
+                          [o.clone() if isinstance(o, torch.Tensor) and o.numel() else None for o in outs]))
+            return out
+        return g
+
+    try:
+        for n in NAMES:
+            setattr(ops, n, wrap(n))
+        with torch.no_grad():
+            torch.manual_seed(1)
+            model(imgs, torch.as_tensor(intr).cuda(), torch.as_tensor(extr).cuda(), torch.tensor([425.0]).cuda(), torch.tensor([935.0]).cuda())
+    finally:
+        for n in NAMES:
+            setattr(ops, n, orig[n])
+    torch.cuda.synchronize()
+    return orig, calls
+
+
+def _same(got, want):
+    got = got if isinstance(got, (tuple, list)) else (got,)
+    return all(w is None or torch.equal(g, w) for g, w in zip(got, want))
+
+
+def test_every_launch_is_the_same_beside_the_fp16_mfma_kernels():
+    assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
+    orig, calls = _capture_forward(1200, 1600, 5)
+    names = [c[0] for c in calls]
+    assert names.count("feature_weight") == 3 and names.count("warp_correlate") == 5 and "refine_fused" in names
+    # the two strongest disturbers of round 6's matrix (profiles/r06_overlap/r06_allvictims.log): a 64-channel fp16-split convolution
+    # and the fused Refinement kernel
+    conv_calls = [c for c in calls if c[0] == "conv2d_f16s"]
+    disturbers = [conv_calls[3], next(c for c in calls if c[0] == "refine_fused")]
+    A, B = torch.cuda.Stream(), torch.cuda.Stream()
+    reps, failures = 12, []
+    with torch.no_grad():
+        for k, (name, a, kw, want) in enumerate(calls):
+            for dname, da, dkw, _ in disturbers:
+                torch.cuda.synchronize()
+                with torch.cuda.stream(B):
+                    for _ in range(120):  # ~12 ms of disturber work; the victim's 12 launches take 0.2-5 ms
+                        orig[dname](*da, **dkw)
+                with torch.cuda.stream(A):
+                    outs = [orig[name](*a, **kw) for _ in range(reps)]
+                    A.synchronize()
+                busy = not B.query()
+                torch.cuda.synchronize()
+                bad = sum(0 if _same(o, want) else 1 for o in outs)
+                if bad:
+                    failures.append(f"call {k} {name} beside {dname}: {bad} of {reps} launches differ from the solo output")
+                elif not busy and name in ("feature_weight", "warp_correlate"):
+                    failures.append(f"call {k} {name} beside {dname}: the disturber finished before the victim (test too weak)")
+    assert not failures, "\n".join(failures)

@@ -78,17 +78,3 @@ def test_recording_pass_refuses_operators_outside_the_library():
             with pytest.raises(PmnError, match="outside"):
                 bad()
     assert (x + 1).sum() > 0 and e.shape == (2, 3)  # outside the mode everything is as usual
-
-
-def test_graph_replay_refuses_several_hardware_queues(monkeypatch):
-    """the HIP-graph mode is only bit-exact on one hardware queue -- it now refuses to be constructed otherwise instead
-    of warning; the launch-plan mode has no such condition."""
-    from patchmatchnet_amd import PmnError
-    from patchmatchnet_amd.graph import GraphedForward, PlannedForward
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    with pytest.raises(PmnError, match="GPU_MAX_HW_QUEUES"):
-        GraphedForward(object())
-    GraphedForward(object(), allow_several_hardware_queues=True)
-    PlannedForward(object())
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "1")
-    GraphedForward(object())
