@@ -152,9 +152,13 @@ def pointwise_mlp(x: np.ndarray, params: Dict[str, np.ndarray], prefix: str, las
     return out
 
 
-def pixelwise_net(similarity: np.ndarray, params, prefix: str) -> Tuple[np.ndarray, np.ndarray]:
-    """models/patchmatch.py:695-702 -- max over D of sigmoid(MLP(sim)).  Returns ([B,1,h,w], argmax [B,h,w])."""
+def pixelwise_net(similarity: np.ndarray, params, prefix: str, responses: Optional[list] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """models/patchmatch.py:695-702 -- max over D of sigmoid(MLP(sim)).  Returns ([B,1,h,w], argmax [B,h,w]); ``responses`` (a list)
+    additionally receives the per-hypothesis responses [B,D,h,w] the max was taken over (the parity tests show with them that every
+    arg-max mismatch at full size is a tie)."""
     resp = pointwise_mlp(similarity, params, prefix, "conv2", sigmoid=True)  # [B,D,h,w]
+    if responses is not None:
+        responses.append(resp)
     return resp.max(axis=1, keepdims=True), resp.argmax(axis=1)
 
 
@@ -318,13 +322,13 @@ def evaluation(ref_feature, src_features: Sequence[np.ndarray], ref_proj, src_pr
         assert len(src_features) == view_weights.shape[1]
     weight_sum = np.full((B, h, w), 1e-5, np.float32)
     sim_sum = np.zeros((B, G, D, h, w), np.float32)
-    vw_list, arg_list = [], []
+    vw_list, arg_list, resp_list = [], [], []
     for i, (src_fea, src_proj) in enumerate(zip(src_features, src_projs)):
         sim = warp_similarity(ref_feature, src_fea, src_proj, ref_proj, depth_sample, G)
         if have_vw:
             vw = view_weights[:, i:i + 1]
         else:
-            vw, arg = pixelwise_net(sim, params, f"{prefix}.pixel_wise_net")
+            vw, arg = pixelwise_net(sim, params, f"{prefix}.pixel_wise_net", resp_list)
             vw_list.append(vw)
             arg_list.append(arg)
         vw = _c(vw)
@@ -339,6 +343,7 @@ def evaluation(ref_feature, src_features: Sequence[np.ndarray], ref_proj, src_pr
     if not have_vw:
         view_weights = np.concatenate(vw_list, axis=1)
         out["view_weight_argmax"] = np.stack(arg_list, axis=1)
+        out["view_weight_responses"] = np.stack(resp_list, axis=1)  # [B,N,D,h,w]
     out["view_weights"] = view_weights
     out["depth"] = regress_depth(depth_sample, prob, is_inverse)
     return out

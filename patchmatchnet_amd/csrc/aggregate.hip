@@ -16,11 +16,7 @@
 #include <cstring>
 
 #include "pmn_common.hpp"
-#ifdef PMN_ATEN_GPU_DIV  // attribution build: index / (D - 1) as ATen's GPU kernel takes it, index * (1.0f / (D - 1))
-#define PMN_DIV_DM1(acc, D) ((acc) * (1.0f / (float)((D) - 1)))
-#else
 #define PMN_DIV_DM1(acc, D) ((acc) / (float)((D) - 1))
-#endif
 
 struct AggArgs {
     const float* cost;     // [B,h,w,D]
@@ -277,15 +273,9 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
             for (int j = 0; j < 4; ++j) {
                 const float x1 = fmaf(x11[j], w11[k], fmaf(x10[j], w10[k], fmaf(x01[j], w01[k], x00[j] * w00[k])));
                 ck[k][j] = fmaf(c11[j], w11[k], fmaf(c10[j], w10[k], fmaf(c01[j], w01[k], c00[j] * w00[k])));
-#ifdef PMN_IEEE_DIV  // attribution build (profiles/r04_ieee_attribution.md): the reference's divisions and expf
-                float t = fabsf(x1 - xc[j]) / a.interval_scale;
-                t = fminf(fmaxf(t, 0.0f), 4.0f);
-                wk[k][j] = pmn_sigmoid(4.0f - 2.0f * t) * fw[k];
-#else
                 float t = fabsf(x1 - xc[j]) * inv_interval;
                 t = fminf(fmaxf(t, 0.0f), 4.0f);
                 wk[k][j] = sigmoid_rcp(4.0f - 2.0f * t) * fw[k];
-#endif
                 wsum[j] = wsum[j] + wk[k][j];
             }
         }
@@ -297,11 +287,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (KMAX <= 9 ? 3 : 1)) void aggregate_regr
     for (int k = 0; k < KMAX; ++k)
         if (k < K) {
 #pragma unroll
-#ifdef PMN_IEEE_DIV
-            for (int j = 0; j < 4; ++j) s[j] = s[j] + ck[k][j] * (wk[k][j] / wsum[j]);
-#else
             for (int j = 0; j < 4; ++j) s[j] = s[j] + ck[k][j] * (wk[k][j] * rsum[j]);
-#endif
         }
 
     // exp(log_softmax) over the D hypotheses of the pixel: max, log-sum-exp, probabilities; then the regression

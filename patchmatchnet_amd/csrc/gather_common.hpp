@@ -54,18 +54,6 @@ __device__ __forceinline__ float pmn_settle(float v) {
 __device__ __forceinline__ float4 pmn_settle4(float4 v) {
     return make_float4(pmn_settle(v.x), pmn_settle(v.y), pmn_settle(v.z), pmn_settle(v.w));
 }
-// probe switches (scripts/build_waitcnt_variants.sh): the PixelwiseNet inputs / the MLP's tail constants separately
-#ifndef PMN_SETTLE_X
-#define PMN_SETTLE_X 1
-#endif
-#ifndef PMN_SETTLE_TAIL
-#define PMN_SETTLE_TAIL 1
-#endif
-#ifndef PMN_SETTLE_W
-#define PMN_SETTLE_W 0
-#endif
-__device__ __forceinline__ float pmn_settle_x(float v) { return PMN_SETTLE_X ? pmn_settle(v) : v; }
-__device__ __forceinline__ float pmn_settle_t(float v) { return PMN_SETTLE_TAIL ? pmn_settle(v) : v; }
 
 // Pointwise MLP G -> 16 -> 8 -> 1 for NI items at once, weights read from LDS (uniform address = broadcast read).
 // Layers 1 and 2 are fused in a ROLLED loop over the 16 hidden units: unit j of every item is produced from weight row
@@ -149,14 +137,6 @@ __device__ __forceinline__ void mlp_pairs_from_lds(const float* __restrict__ W, 
             w1c[4] = c1.x; w1c[5] = c1.y; w1c[6] = c1.z; w1c[7] = c1.w;
         }
         float t0 = W[20 * j + 16];
-#if PMN_SETTLE_W  // the weight rows of the rolled loop (never caught failing, unlike the tail constants below: see lesson 46)
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < G) w0[g] = pmn_settle(w0[g]);
-            w1c[g] = pmn_settle(w1c[g]);
-        }
-        t0 = pmn_settle(t0);
-#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             pmn_f2 acc = pmn_f2{w0[0], w0[0]} * x[p][0];
@@ -172,11 +152,11 @@ __device__ __forceinline__ void mlp_pairs_from_lds(const float* __restrict__ W, 
     const float4 ta = reinterpret_cast<const float4*>(W + 320)[0], tb = reinterpret_cast<const float4*>(W + 320)[1];
     const float4 wa = reinterpret_cast<const float4*>(W + 328)[0], wb = reinterpret_cast<const float4*>(W + 328)[1];
     // (read from LDS and used by packed instructions right away: lesson 46)
-    const float t1[8] = {pmn_settle_t(ta.x), pmn_settle_t(ta.y), pmn_settle_t(ta.z), pmn_settle_t(ta.w), pmn_settle_t(tb.x), pmn_settle_t(tb.y),
-                         pmn_settle_t(tb.z), pmn_settle_t(tb.w)};
-    const float w2[8] = {pmn_settle_t(wa.x), pmn_settle_t(wa.y), pmn_settle_t(wa.z), pmn_settle_t(wa.w), pmn_settle_t(wb.x), pmn_settle_t(wb.y),
-                         pmn_settle_t(wb.z), pmn_settle_t(wb.w)};
-    const float b2 = pmn_settle_t(W[336]);
+    const float t1[8] = {pmn_settle(ta.x), pmn_settle(ta.y), pmn_settle(ta.z), pmn_settle(ta.w), pmn_settle(tb.x), pmn_settle(tb.y),
+                         pmn_settle(tb.z), pmn_settle(tb.w)};
+    const float w2[8] = {pmn_settle(wa.x), pmn_settle(wa.y), pmn_settle(wa.z), pmn_settle(wa.w), pmn_settle(wb.x), pmn_settle(wb.y),
+                         pmn_settle(wb.z), pmn_settle(wb.w)};
+    const float b2 = pmn_settle(W[336]);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         pmn_f2 h = a1[p][0] + pmn_f2{t1[0], t1[0]};

@@ -118,18 +118,6 @@ __device__ __forceinline__ PmnCorners load_corners(const char* __restrict__ sbas
 
 template <int LPG, int CG>
 __device__ __forceinline__ float blend_corners(const PmnCorners& c, float4 w4, const float4 refq) {
-#if defined(PMN_DBG_BLEND) && PMN_DBG_BLEND == 1  // lesson 46 probe: the same operations without packed math
-    {
-        float r[4];
-        const float t00[4] = {c.t00.x, c.t00.y, c.t00.z, c.t00.w}, t01[4] = {c.t01.x, c.t01.y, c.t01.z, c.t01.w};
-        const float t10[4] = {c.t10.x, c.t10.y, c.t10.z, c.t10.w}, t11[4] = {c.t11.x, c.t11.y, c.t11.z, c.t11.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = fmaf(t11[k], w4.w, fmaf(t10[k], w4.z, fmaf(t01[k], w4.y, t00[k] * w4.x)));
-        float s = fmaf(r[3], refq.w, fmaf(r[2], refq.z, fmaf(r[1], refq.y, r[0] * refq.x)));
-        if (LPG == 2) s += pmn_pair_swap(s);
-        return s * (1.0f / CG);
-    }
-#endif
     const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
     pmn_f2 lo = pmn_f2{c.t00.x, c.t00.y} * wa;
     pmn_f2 hi = pmn_f2{c.t00.z, c.t00.w} * wa;
@@ -467,30 +455,12 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
                 for (int i = 0; i < NBP; ++i) {
                     const int r = (d + i - dc0) * NPIX;
                     wq[i] = pmn_settle4(rw[r]);  // LDS -> packed math (blend_corners): lesson 46
-#if defined(PMN_DBG_LANE) && PMN_DBG_LANE == 4  // lesson 46 probe: taps that do not come from the LDS records
-                    wq[i] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
-                    cn[i] = load_corners<C>(sbase, (unsigned)(min(yB, hs - 2) * ws + min(xB + d + i, ws - 2)) * (C * 4) + lane_bytes, row_bytes);
-#elif defined(PMN_DBG_LANE) && PMN_DBG_LANE == 7  // ... address from the LDS record, constant weights
-                    wq[i] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
                     cn[i] = load_corners<C>(sbase, (unsigned)ro[r] * (C * 4) + lane_bytes, row_bytes);
-#elif defined(PMN_DBG_LANE) && PMN_DBG_LANE == 8  // ... weights from the LDS record, address from the pixel
-                    cn[i] = load_corners<C>(sbase, (unsigned)(min(yB, hs - 2) * ws + min(xB + d + i, ws - 2)) * (C * 4) + lane_bytes, row_bytes);
-#elif defined(PMN_DBG_LANE) && PMN_DBG_LANE == 3  // ... no global loads: the record itself
-                    cn[i].t00 = cn[i].t01 = cn[i].t10 = cn[i].t11 = make_float4((float)ro[r], 1.f, 2.f, 3.f);
-#else
-                    cn[i] = load_corners<C>(sbase, (unsigned)ro[r] * (C * 4) + lane_bytes, row_bytes);
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NBP; ++i) {
-#if defined(PMN_DBG_LANE) && PMN_DBG_LANE == 3
-                    const float s = wq[i].x + 2.0f * wq[i].y + 4.0f * wq[i].z + 8.0f * wq[i].w + cn[i].t00.x;
-#elif defined(PMN_DBG_LANE) && PMN_DBG_LANE == 5  // pure arithmetic through the LDS hand-over
-                    const float s = (float)(grp * 64 + d + i) + 0.001f * (float)(tile & 1023);
-#else
                     const float s = blend_corners<LPG, CG>(cn[i], wq[i], refq);
-#endif
                     if (owner) simt[gB * SS + (d + i) * NPIX + grp] = s;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -544,15 +514,7 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
 #pragma unroll
             for (int j = 0; j < NIT; ++j) {
                 const int d = dA0 + j * DSTEP;
-#if defined(PMN_DBG_NEIGHBOR) && PMN_DBG_NEIGHBOR == 6  // no LDS at all: the store itself
-                if (d < D) a.out[((size_t)b * D + d) * hw + pA] = (float)(pixA + 1000 * d) + 0.001f * (float)(tile & 1023);
-#elif defined(PMN_DBG_NEIGHBOR) && PMN_DBG_NEIGHBOR == 1  // lesson 46 probe: the similarity the item role read (group 0 + 2 * group 1)
-                if (d < D) a.out[((size_t)b * D + d) * hw + pA] = simt[0 * SS + d * NPIX + pixA] + 2.0f * simt[1 * SS + d * NPIX + pixA];
-#elif defined(PMN_DBG_NEIGHBOR) && PMN_DBG_NEIGHBOR == 2  // the MLP's output before the sigmoid
-                if (d < D) a.out[((size_t)b * D + d) * hw + pA] = o[j];
-#else
                 if (d < D) a.out[((size_t)b * D + d) * hw + pA] = pmn_sigmoid(o[j]);
-#endif
             }
             return;
         }
@@ -812,7 +774,7 @@ __global__ __launch_bounds__(PMN_BLOCK, PMN_PW_WAVES) void pixelwise_wave_kernel
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {  // LDS -> packed MLP: lesson 46 (a second loop: all eight reads in flight, then the moves)
-                x[0][g] = pmn_settle_x(x[0][g]); x[1][g] = pmn_settle_x(x[1][g]);
+                x[0][g] = pmn_settle(x[0][g]); x[1][g] = pmn_settle(x[1][g]);
             }
         }
         unsigned long long best = 0ull;

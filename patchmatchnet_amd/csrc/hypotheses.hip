@@ -9,13 +9,8 @@
 #include <cstring>
 
 #include "pmn_common.hpp"
-#ifdef PMN_ATEN_GPU_DIV  // attribution build: u / 48 as ATen's GPU kernel takes it, u * (1.0f / 48.0f)
-#define PMN_DIV48(u) ((u) * (1.0f / 48.0f))
-#define PMN_DIV48R(u) ((u) * (1.0f / 48.0f))
-#else
 #define PMN_DIV48(u) ((u) / 48.0f)
 #define PMN_DIV48R(u) pmn_div_by((u), 48.0f, r48)
-#endif
 
 struct HypArgs {
     const float* noise;      // [B,48,h,w] or null

@@ -137,15 +137,9 @@ __device__ __forceinline__ float pmn_div(float n, float d) { return pmn_div_by(n
 __device__ __forceinline__ PmnPose pmn_make_pose(const float* __restrict__ P, float x, float y, int h, int w) {
 #pragma clang fp contract(off)
     PmnPose q;
-#ifdef PMN_POSE_FMA  // attribution build (scripts/rocm_parity_probe.py): rot @ [x y 1]^T as a GEMM's k-ordered fma chain (what a BLAS on the GPU does)
-    q.rx = fmaf(P[2], 1.0f, fmaf(P[1], y, P[0] * x));
-    q.ry = fmaf(P[6], 1.0f, fmaf(P[5], y, P[4] * x));
-    q.rz = fmaf(P[10], 1.0f, fmaf(P[9], y, P[8] * x));
-#else
     q.rx = (P[0] * x + P[1] * y) + P[2];
     q.ry = (P[4] * x + P[5] * y) + P[6];
     q.rz = (P[8] * x + P[9] * y) + P[10];
-#endif
     q.tx = P[3];
     q.ty = P[7];
     q.tz = P[11];
@@ -171,11 +165,7 @@ __device__ __forceinline__ bool pmn_pose_position(const PmnPose& q, float d, int
     }
     const float rz = pmn_rcp_refined(pz);
     const float gx = pmn_div_by(px, pz, rz), gy = pmn_div_by(py, pz, rz);                  // proj_xyz[:, :2] / z
-#ifdef PMN_ATEN_GPU_DIV  // attribution build: ATen's GPU division by a host scalar is a multiplication by the rounded reciprocal
-    const float xn = gx * pmn_uniform(pmn_div(1.0f, q.cx)) - 1.0f, yn = gy * pmn_uniform(pmn_div(1.0f, q.cy)) - 1.0f;
-#else
     const float xn = pmn_div_by(gx, q.cx, q.rcx) - 1.0f, yn = pmn_div_by(gy, q.cy, q.rcy) - 1.0f;  // x / ((w - 1) / 2) - 1
-#endif
     ix = pmn_unnorm_align(xn, ws);
     iy = pmn_unnorm_align(yn, hs);
     return front;
@@ -198,13 +188,8 @@ __device__ __forceinline__ void pmn_neighbor_position(float x, float y, int dy, 
     const float rcx = pmn_uniform(pmn_rcp_refined(cx)), rcy = pmn_uniform(pmn_rcp_refined(cy));  // loop-invariant, in SGPRs
     float X = x + ((float)dx + offx);
     float Y = y + ((float)dy + offy);
-#ifdef PMN_ATEN_GPU_DIV
-    float xn = X * pmn_uniform(pmn_div(1.0f, cx)) - 1.0f;
-    float yn = Y * pmn_uniform(pmn_div(1.0f, cy)) - 1.0f;
-#else
     float xn = pmn_div_by(X, cx, rcx) - 1.0f;
     float yn = pmn_div_by(Y, cy, rcy) - 1.0f;
-#endif
     ix = fminf(fmaxf(pmn_unnorm_noalign(xn, w), 0.0f), (float)(w - 1));
     iy = fminf(fmaxf(pmn_unnorm_noalign(yn, h), 0.0f), (float)(h - 1));
 }

@@ -53,9 +53,11 @@ class FeatureNet(nn.Module):
         # verification switch, not a performance choice: False = the FPN head layer by layer in the reference's order instead of the
         # host-composed 1x1 convolutions (an algebraic re-association)
         self.fold_fpn = True
-        # research build only (PMN_EXPERIMENTAL=1, libpmn_hip_experimental.so): rounds 1-2's fp32 alternatives, read when f16_split is
-        # False -- Winograd 3x3 / 5x5-stride-2, fp32 MFMA wide layers, the VALU form of the FPN's 1/8 level.  Ignored by the product.
-        self.research = dict(winograd=False, winograd5=False, mfma_convs=False, fpn8_valu=False)
+        # verification switch (test hook): the FPN's 1/8 level through the VALU kernel (pmn_fpn_level) instead of the fp32 matrix cores
+        self.fpn8_valu = False
+        # None in the product.  patchmatchnet_amd/research.py (PMN_EXPERIMENTAL=1 only) installs a callable (layer index, input) ->
+        # output-or-None here to run rounds 1-2's fp32 alternatives for single layers when f16_split is False.
+        self.layer_hook = None
 
     # ---- HIP execution (pmn_conv2d): same parameters, channels-last activations, BN/ReLU/FPN-add fused ----------------
     _SPEC = [(3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1), (3, 1, 1), (5, 2, 2), (3, 1, 1),
@@ -82,22 +84,6 @@ class FeatureNet(nn.Module):
                         pk[f"conv{i}_f16s"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
                     except params.F16DomainError as e:
                         f16_ok, self.f16_domain_error = False, f"conv{i}: {e}"
-                if not _lib.experimental():
-                    continue
-                if (cv.in_channels, cv.out_channels, cv.kernel_size[0], cv.stride[0]) in ops.MFMA_CONV_SHAPES:
-                    w, s = params.pack_conv_mfma(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
-                                                 eps=m.bn.eps)
-                    pk[f"conv{i}_mfma"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                if cv.kernel_size[0] == 3 and cv.stride[0] == 1 and cv.in_channels == cv.out_channels and \
-                        cv.in_channels in (16, 32, 64):
-                    w, s = params.pack_conv_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var),
-                                                 eps=m.bn.eps)
-                    pk[f"conv{i}_wino"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
-                if cv.kernel_size[0] == 5 and cv.stride[0] == 2 and \
-                        (cv.in_channels, cv.out_channels) in ((8, 16), (16, 32), (32, 64)):
-                    w, s = params.pack_conv5x5s2_wino(cv.weight, bn=(m.bn.weight, m.bn.bias, m.bn.running_mean,
-                                                                     m.bn.running_var), eps=m.bn.eps)
-                    pk[f"conv{i}_wino5"] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             m1 = self.conv1
             try:
                 w, s = params.pack_stem_conv1_f16s(m1.conv.weight, bn=(m1.bn.weight, m1.bn.bias, m1.bn.running_mean, m1.bn.running_var),
@@ -150,12 +136,8 @@ class FeatureNet(nn.Module):
                 continue
             if self.f16_split and f"conv{i}_f16s" in pk:  # fp16 matrix cores, split operands
                 t = ops.conv2d_f16s(t, *pk[f"conv{i}_f16s"], k, s, relu=True)
-            elif self.research["winograd"] and f"conv{i}_wino" in pk:  # research build: Winograd F(2x2,3x3), fp32 matrix cores
-                t = ops.conv3x3_wino(t, *pk[f"conv{i}_wino"], relu=True)
-            elif self.research["winograd5"] and f"conv{i}_wino5" in pk:  # research build: 5x5 stride 2 as four Winograd sub-convolutions
-                t = ops.conv5x5s2_wino(t, *pk[f"conv{i}_wino5"], relu=True)
-            elif self.research["mfma_convs"] and f"conv{i}_mfma" in pk:  # research build: fp32 implicit GEMM on the matrix cores
-                t = ops.conv2d_mfma(t, *pk[f"conv{i}_mfma"], k, s, p, relu=True)
+            elif self.layer_hook is not None and (hooked := self.layer_hook(i, t)) is not None:  # research build only
+                t = hooked
             else:  # fp32 VALU direct convolution
                 w, sh = pk[f"conv{i}"]
                 t = ops.conv2d(t, w, sh, getattr(self, f"conv{i}").conv.out_channels, k, s, p, relu=True)
@@ -165,7 +147,7 @@ class FeatureNet(nn.Module):
         if self.fold_fpn:
             # the FPN head is linear: its 1x1 convolutions are composed on the host (params.fold_fpn) and each level is one
             # bandwidth-bound kernel -- the 64-channel intermediates at 1/4 and 1/2 resolution never exist
-            if self.research["fpn8_valu"]:  # (test hook: the VALU form of the same level)
+            if self.fpn8_valu:  # (test hook: the VALU form of the same level)
                 f3, u8 = ops.fpn_level(eighth, None, *pk["fpn8"], ca=64)
             else:  # 64 -> 112 channels: a GEMM, on the fp32 matrix cores (pmn_conv2d_mfma's 1x1 form)
                 f3, u8 = ops.pointwise_split_mfma(eighth, *pk["fpn8_mfma"], cout=112, ca=64)

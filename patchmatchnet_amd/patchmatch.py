@@ -242,7 +242,7 @@ class PatchMatch(nn.Module):
         # fit float16's range; otherwise, and with False, pmn_conv2d (fp32 VALU), one launch per head.
         self.f16_split = True
         self.f16_domain_error: Optional[str] = None
-        self.research = dict(mfma_offset_heads=False)  # research build only (PMN_EXPERIMENTAL=1): round 2's fp32 MFMA planar form
+        self.heads_hook = None  # None in the product; patchmatchnet_amd/research.py may install round 2's fp32 MFMA form of the heads
         self._heads = None
         self._heads_key = None
         self._ptable = params.propagation_table(propagate_neighbors, self.dilation) if propagate_neighbors > 0 else None
@@ -271,9 +271,6 @@ class PatchMatch(nn.Module):
                         pk["f16s_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
                     except params.F16DomainError as e:
                         self.f16_domain_error = f"offset heads: {e}"
-                if _lib.experimental() and (self.eval_conv.in_channels, self.dilation) in ops.MFMA_HEAD_SHAPES and rows <= 64:
-                    w, s = params.pack_conv_mfma(wcat, bias=bcat)
-                    pk["mfma_" + name] = (torch.from_numpy(w).to(dev), torch.from_numpy(s).to(dev))
             if self.f16_domain_error is not None:
                 warnings.warn(f"PatchMatch stage {self.stage}: " + self.f16_domain_error + " -- using pmn_conv2d (fp32)", RuntimeWarning,
                               stacklevel=2)
@@ -307,16 +304,13 @@ class PatchMatch(nn.Module):
         if self.hip_offset_heads:
             # offset heads as HIP convolutions on the channels-last reference feature, planar [B,2K,h,w] output
             pk = self._packed_heads()
-            key = "mfma_both" if propagate_any else "mfma_eval_only"
             fkey = "f16s_both" if propagate_any else "f16s_eval_only"
             if self.f16_split and fkey in pk:  # fp16 matrix cores, split operands (round 3)
                 n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
                 a_, b_ = ops.offset_heads_f16s(ref_nhwc, *pk[fkey], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
                 propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)
-            elif self.research["mfma_offset_heads"] and key in pk:  # research build
-                n_p, n_e = (2 * self.propagate_neighbors if propagate_any else 0), 2 * self.evaluate_neighbors
-                a_, b_ = ops.offset_heads_mfma(ref_nhwc, *pk[key], n_p + n_e, n_p if propagate_any else n_e, self.dilation)
-                propa_offsets, eval_offsets = (a_, b_) if propagate_any else (None, a_)
+            elif self.heads_hook is not None and (hooked := self.heads_hook(self, ref_nhwc, propagate_any)) is not None:  # research build
+                propa_offsets, eval_offsets = hooked
             else:
                 propa_offsets = ops.conv2d(ref_nhwc, *pk["propa"], 2 * self.propagate_neighbors, 3, 1, self.dilation,
                                            self.dilation, out_nchw=True) if propagate_any else None

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 6): the -DPMN_IEEE_DIV / -DPMN_ATEN_GPU_DIV / -DPMN_POSE_FMA blocks no longer live in the product sources: apply
+# scripts/experiments/source_switches/attribution_and_probe_switches.patch to a scratch copy of patchmatchnet_amd/csrc first.
 # Attribution build of the PRODUCT library (profiles/r04_ieee_attribution.md): gather_corr.hip and aggregate.hip with -DPMN_IEEE_DIV
 # (the reference's own chain of IEEE divisions / expf instead of v_rcp + Newton / v_exp) -> scripts/microbench/variants/libpmn_ieee.so
 set -e

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 6): the -DPMN_IEEE_DIV / -DPMN_ATEN_GPU_DIV / -DPMN_POSE_FMA blocks no longer live in the product sources: apply
+# scripts/experiments/source_switches/attribution_and_probe_switches.patch to a scratch copy of patchmatchnet_amd/csrc first.
 # Round 5 A/B builds of libpmn_hip.so for the PixelwiseNet launch (scripts/gpu_r5_pixelwise_ab.sh runs them on one box):
 #   base   gather_corr.hip of the given git revision (default: round 4's last commit c9b86bd): flat corner loads, workgroup-tile PixelwiseNet
 #   g0     this tree, -DPMN_PW=0: global corner loads, workgroup-tile PixelwiseNet kernel

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Probe builds for DESIGN_LESSONS.md lesson 46 (output build/wc/libpmn_hip_<variant>.so; only gather_corr.hip differs):
-#   fz     -mllvm -amdgpu-waitcnt-forcezero : an s_waitcnt 0 after every instruction -- if the overlap corruption disappears, some wait
-#          the compiler left out (or a hazard its tables lack) is what the co-running kernel exposes
-#   O1     the same source at -O1 (different schedule, same semantics)
+#   nosettle  -DPMN_NO_SETTLE: lesson 46's fix compiled out -- tests/test_overlap_gpu.py must FAIL on it (scripts/gpu_r6_suite.sh)
+# (The builds that located the defect -- -DPMN_DBG_NEIGHBOR / _LANE / _BLEND, -DPMN_SETTLE_X/_TAIL/_W, -O1, -amdgpu-waitcnt-forcezero --
+#  need scripts/experiments/source_switches/attribution_and_probe_switches.patch applied first; their results are in
+#  profiles/r06_overlap/r06_variants.log and r06_fixcheck.log.)
 set -e
 cd "$(dirname "$0")/.."
 CS=patchmatchnet_amd/csrc
@@ -10,11 +11,10 @@ make -s -C $CS -j8
 mkdir -p build/wc
 FLAGS="-std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -I$CS"
 OTHERS=$(ls $CS/*.o | grep -v '\.x\.o' | grep -v gather_corr.o)
-build() { # name opt flags...
+build() { # name flags...
   local name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $CS/gather_corr.hip -o build/wc/gather_corr_$name.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o build/wc/libpmn_hip_$name.so build/wc/gather_corr_$name.o $OTHERS
   echo "built build/wc/libpmn_hip_$name.so"
 }
-build rows -O3 -DPMN_SETTLE_W=1 &
-wait
+build nosettle -O3 -DPMN_NO_SETTLE

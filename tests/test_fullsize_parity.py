@@ -59,11 +59,37 @@ def _configs(kw):
                                    kw["patchmatch_num_sample"], kw["propagate_neighbors"], kw["evaluate_neighbors"])
 
 
-def _argmax_check(got_idx, got_vw, want_idx, want_vw, tie=1e-4):
-    """Arg-max over D of the PixelwiseNet response: exact except at fp32 near-ties, where either index gives the same weight."""
+def _argmax_check(got_idx, got_vw, want_idx, want_vw, tie=1e-4, want_resp=None, report=None):
+    """Arg-max over D of the PixelwiseNet response: exact except at fp32 near-ties, where either index gives the same weight.
+    ``want_resp`` [B,N,D,h,w] = the oracle's own per-hypothesis responses: at every mismatch the gap between the oracle's response at
+    ITS index and at the index this engine chose is then measured in ulps of the response (the north star's "bit-exact view_weights
+    indices" can only fail where two hypotheses tie at fp32 resolution) and put into ``report``."""
     bad = got_idx != want_idx
     frac = float(bad.mean())
     assert frac < 5e-4, frac  # measured 1.1e-4 of (pixel, view) pairs at cfg-2 (150 K pairs x 64 hypotheses)
+    if want_resp is not None and bad.any():
+        b_, v_, y_, x_ = np.nonzero(bad)
+        r_own = want_resp[b_, v_, want_idx[bad].astype(np.int64), y_, x_].astype(np.float32)
+        r_eng = want_resp[b_, v_, got_idx[bad].astype(np.int64), y_, x_].astype(np.float32)
+        ulp = np.spacing(np.abs(r_own))
+        gap = (r_own.astype(np.float64) - r_eng.astype(np.float64)) / ulp
+        assert (gap >= 0).all()
+        hist = {str(k): int((np.round(gap) == k).sum()) for k in range(0, 9)}
+        hist[">8"] = int((np.round(gap) > 8).sum())
+        if report is not None:
+            report["view_weight_argmax_mismatches"] = int(bad.sum())
+            report["view_weight_argmax_pairs"] = int(bad.size)
+            report["argmax_mismatch_gap_in_ulps_of_the_oracle_response_max"] = float(gap.max())
+            report["argmax_mismatch_gap_in_ulps_histogram"] = hist
+        # a mismatch is admitted only where the oracle's two responses are closer to each other than the two IMPLEMENTATIONS are on
+        # the pairs they agree about (the noise between two correct fp32 evaluations of the same net: fma contraction inside the
+        # oracle's C, OCML's expf vs glibc's): then either ordering is a correct answer
+        noise = float(np.abs(got_vw.astype(np.float64) - want_vw)[~bad].max()) if (~bad).any() else 0.0
+        gap_abs = r_own.astype(np.float64) - r_eng.astype(np.float64)
+        if report is not None:
+            report["argmax_mismatch_gap_abs_max"] = float(gap_abs.max())
+            report["view_weight_noise_between_implementations_abs_max"] = noise
+        assert float(gap_abs.max()) <= 2.0 * noise + 4.0 * float(ulp.max()), (float(gap_abs.max()), noise)
     if bad.any():  # ... every one of them a near-tie: the two hypotheses' responses differ by less than the fp32 noise of the
         # response itself (measured: weights differ by <= 3.4e-6 at cfg-2, <= 3.2e-5 at cfg-5's 10 views -- inside the 1e-4 the
         # weights themselves are held to), so either index yields the same weight
@@ -147,7 +173,8 @@ def test_chained_cascade_from_hip_featurenet(scene, H, W, nsrc):
             assert rel.max() < 1e-3, (stage, it, float(rel.max()))
             if stage == 3 and it == 0:
                 worst["view_weight_argmax_mismatch_frac"] = _argmax_check(
-                    n(rec["view_weight_argmax"]), n(rec["view_weights"]), orec["view_weight_argmax"], orec["view_weights"])
+                    n(rec["view_weight_argmax"]), n(rec["view_weights"]), orec["view_weight_argmax"], orec["view_weights"],
+                    want_resp=orec.get("view_weight_responses"), report=worst)
                 assert GU.abs_err(n(rec["view_weights"]), orec["view_weights"]) < 1e-4
             prev_depth = n(rec["depth"])[:, None]
             if stage == 3 and it == 0:
@@ -172,6 +199,68 @@ def test_chained_cascade_from_hip_featurenet(scene, H, W, nsrc):
     _, idx_or = O.confidence(oscore, (H, W))
     worst["depth_index_mismatch_frac"] = _index_check(n(idx_hip), n(score_hip), idx_or)
     _report(test="chained_cascade", scene=scene, H=H, W=W, n_src=nsrc, **worst)
+
+
+def _scene_against_reference(P, fixture, gates):
+    """Free-running forward from the images against the reference's own CPU forward stored in ``fixture`` (made by
+    tests/golden/make_golden.py --only scene3 / scene5; maps kept at every ``stride``-th pixel)."""
+    model, params, kw = _model(P)
+    g = GU.load_npz(fixture)
+    H, W, nv, st = int(g["H"]), int(g["W"]), int(g["n_views"]), int(g["stride"])
+    imgs, intr, extr, gt = synth.render_scene(nv, H, W, int(g["scene_seed"]))
+    assert synth.scene_digest(imgs) == str(g["scene_digest"]), "this host renders a different scene than the golden was made on"
+    noise = torch.rand(1, 48, H // 8, W // 8, generator=torch.Generator().manual_seed(int(g["noise_seed"]))).to(DEV)
+    dbg = {}
+    with torch.no_grad():
+        depth, conf, dpm = model([im.to(DEV) for im in imgs], t(intr), t(extr), torch.tensor([425.0], device=DEV),
+                                 torch.tensor([935.0], device=DEV), noise=noise, debug=dbg)
+    torch.cuda.synchronize()
+    sub = lambda a: a[..., ::st, ::st]  # noqa: E731
+    rep = {"fixture": fixture, "H": H, "W": W, "n_src": nv - 1, "stride": st}
+
+    def stats(name, got, want):
+        rel = np.abs(sub(got).astype(np.float64) - want) / np.abs(want)
+        rep[name] = {"max": float(rel.max()), "p999": float(np.quantile(rel, 0.999)), "p99": float(np.quantile(rel, 0.99)),
+                     "frac_over_1e-3": float((rel > 1e-3).mean()), "frac_over_1e-4": float((rel > 1e-4).mean())}
+        return rep[name]
+
+    for s_ in (3, 2, 1):
+        for it, d in enumerate(dpm[s_]):
+            stats(f"s{s_}_it{it + 1}", n(d), g[f"s{s_}_it{it + 1}_depth_out"])
+    fin = stats("final", n(depth), g["depth"])
+    err_gt = np.abs(n(depth)[0, 0] - gt.numpy())
+    rep["vs_ground_truth_mm"] = {"median": float(np.median(err_gt)), "p90": float(np.quantile(err_gt, 0.9))}
+    rep["view_weights_abs_max"] = GU.abs_err(sub(n(dbg[3][0]["view_weights"])), g["view_weights"])
+    _, idx_hip = P.ops.confidence(dbg[1][-1]["score"].contiguous(), H, W, want_index=True)
+    rep["depth_index_mismatch_frac"] = float((sub(n(idx_hip)).astype(np.int64) != g["depth_index"].astype(np.int64)).mean())
+    rep["confidence_frac_over_1e-3"] = float((np.abs(sub(n(conf)) - g["confidence"]) > 1e-3).mean())
+    _report(test=fixture.replace(".npz", "_vs_reference"), **rep)
+    # the stage-3 first iteration has no history to amplify: strict
+    assert rep["s3_it1"]["max"] < 1e-4, rep["s3_it1"]
+    assert rep["view_weights_abs_max"] < 1e-4, rep["view_weights_abs_max"]
+    for k in ("s3_it2", "s2_it1", "s2_it2", "s1_it1", "final"):
+        assert rep[k]["p99"] < 1e-5, (k, rep[k])
+        assert rep[k]["frac_over_1e-3"] < gates["frac"], (k, rep[k])
+        assert rep[k]["max"] < gates["max"], (k, rep[k])
+    assert fin["p999"] < gates["p999"], fin
+    assert rep["vs_ground_truth_mm"]["median"] < 1.0, rep["vs_ground_truth_mm"]
+    return rep
+
+
+def test_cfg3_scene_end_to_end_against_the_reference_itself():
+    """BASELINE configs[2] (Tanks & Temples shape: 1920x1056, N=7), FREE-RUNNING from the images, against the reference's own CPU
+    forward (tests/golden/cfg3_scene.npz, every second pixel).  Round 5 gated free-running parity against the reference's CPU path at
+    configs[1] only.  Gates: the bulk at the north star (p99 <= 1e-5); the soft-arg-max flips (the reference's
+    own CPU<->ROCm distance is 5.4e-4 of the pixels, profiles/r05_rocm_parity.md) at 1.5x what this configuration measures."""
+    P = _gpu()
+    _scene_against_reference(P, "cfg3_scene.npz", dict(frac=2.5e-4, max=2.5e-2, p999=3e-4))
+
+
+def test_cfg5_scene_end_to_end_against_the_reference_itself():
+    """BASELINE configs[4] (ETH3D shape: 3072x2048, N=10, one GPU's share), the same way (tests/golden/cfg5_scene.npz, every fourth
+    pixel in both directions)."""
+    P = _gpu()
+    _scene_against_reference(P, "cfg5_scene.npz", dict(frac=2.5e-4, max=2.5e-2, p999=3e-4))
 
 
 def test_cfg2_scene_end_to_end_against_the_reference_itself():
@@ -302,7 +391,7 @@ def test_fullsize_stage_against_oracle_cfg3_cfg5(stage, n_src, H, W):
                 assert worst["view_weights_abs_max"] < (1e-4 if n_src <= 7 else 2e-4)
                 worst["view_weight_argmax_mismatch_frac"] = _argmax_check(
                     n(rec["view_weight_argmax"]), n(rec["view_weights"]), orec["view_weight_argmax"], orec["view_weights"],
-                    tie=1e-4 if n_src <= 7 else 2e-4)
+                    tie=1e-4 if n_src <= 7 else 2e-4, want_resp=orec.get("view_weight_responses"), report=worst)
         rel = np.abs(n(rec["depth"]) - orec["depth"]) / orec["depth"]
         worst[f"it{it + 1}_depth_rel_max"] = float(rel.max())
         assert rel.max() < 1e-3, (it, float(rel.max()))
@@ -355,12 +444,17 @@ def test_end_to_end_from_images_both_featurenets(hip_feature_net):
     assert mx < 1e-4, mx  # measured 1.6e-6 (both FeatureNet paths, profiles/r02_parity_report.jsonl); 2e-2 was allowed in round 1
 
 
-def _identical_inputs_against_rocm(ref, b_feats, ref_image, Kd, Ed, dmin, dmax, d_depth, d_dpm, vw_engine, stats):
+def _identical_inputs_against_rocm(ref, b_feats, ref_image, Kd, Ed, dmin, dmax, d_depth, d_dpm, vw_engine, stats, cpu_ref=None,
+                                   attribution=None):
     """The reference's stage modules on ROCm (``ref`` = the pinned-draw archive on the device) are handed THIS ENGINE's previous-stage
     depth and view weights (nearest x2, models/net.py:272-275), the reference's own features ``b_feats`` and torch-on-ROCm projections
     (models/net.py:225-231); iteration 1 of every stage and the refinement are then one call of each side on the same tensors -- the
     north star's "identical inputs" clause against the GPU path; iteration 2 has one free step inside the stage.  ``d_depth`` /
-    ``d_dpm`` / ``vw_engine``: this engine's outputs on the same features.  Returns {stage-iteration or "final": stats}."""
+    ``d_dpm`` / ``vw_engine``: this engine's outputs on the same features.  Returns {stage-iteration or "final": stats}.
+
+    ``cpu_ref`` (the same archive loaded on the CPU) + ``attribution`` (a dict): for every first iteration with a pixel beyond 1e-3
+    of the reference-on-ROCm, the reference's OWN CPU path is run on the very same tensors and, per such pixel, attribution receives
+    {engine_vs_rocm, engine_vs_cpu, rocm_vs_cpu}: whose number is the outlier."""
     Fn = torch.nn.functional
     depth_in, vw_in = torch.empty(0, device=DEV), torch.empty(0, device=DEV)
     forced, scale = {}, 0.125
@@ -377,6 +471,21 @@ def _identical_inputs_against_rocm(ref, b_feats, ref_image, Kd, Ed, dmin, dmax, 
                 depth_min=dmin, depth_max=dmax, depth=depth_in, view_weights=vw_in)
             for it, d in enumerate(depths):
                 forced[f"s{stage}_it{it + 1}"] = stats(n(d_dpm[stage][it]), n(d))
+            rel1 = np.abs(n(d_dpm[stage][0]).astype(np.float64) - n(depths[0])) / np.abs(n(depths[0]))
+            if cpu_ref is not None and attribution is not None and (rel1 > 1e-3).any():
+                c = lambda x: x.detach().cpu()  # noqa: E731
+                cdepths, _, _ = getattr(cpu_ref, f"patchmatch_{stage}")(
+                    ref_feature=c(b_feats[0][stage]), src_features=[c(f[stage]) for f in b_feats[1:]], ref_proj=c(pl[0]),
+                    src_projs=[c(x) for x in pl[1:]], depth_min=c(dmin), depth_max=c(dmax), depth=c(depth_in), view_weights=c(vw_in))
+                cpu1 = cdepths[0].numpy().astype(np.float64)
+                eng1, roc1 = n(d_dpm[stage][0]).astype(np.float64), n(depths[0]).astype(np.float64)
+                where = np.argwhere(rel1 > 1e-3)
+                attribution[f"s{stage}_it1"] = [
+                    {"pixel": [int(v) for v in ix], "engine_vs_rocm": float(rel1[tuple(ix)]),
+                     "engine_vs_cpu": float(abs(eng1[tuple(ix)] - cpu1[tuple(ix)]) / abs(cpu1[tuple(ix)])),
+                     "rocm_vs_cpu": float(abs(roc1[tuple(ix)] - cpu1[tuple(ix)]) / abs(cpu1[tuple(ix)]))} for ix in where[:64]]
+                attribution[f"s{stage}_it1_engine_vs_cpu_all_pixels_max"] = float((np.abs(eng1 - cpu1) / np.abs(cpu1)).max())
+                attribution[f"s{stage}_it1_rocm_vs_cpu_all_pixels_max"] = float((np.abs(roc1 - cpu1) / np.abs(cpu1)).max())
             if stage > 1:
                 depth_in = Fn.interpolate(d_dpm[stage][-1].detach(), scale_factor=2.0, mode="nearest")
                 vw_in = Fn.interpolate(vw_engine if stage == 3 else vw_in, scale_factor=2.0, mode="nearest")
@@ -420,11 +529,14 @@ def test_identical_inputs_against_the_reference_on_rocm_cfg3_cfg5(H, W, nsrc, ri
         d_depth, _, d_dpm = model([im.clone() for im in dimgs], t(intr), t(extr), dmin, dmax, noise=noise,
                                   features=[{s: f[s].contiguous() for s in (1, 2, 3)} for f in b_feats], debug=d_dbg)
     torch.cuda.synchronize()
+    cpu_ref = torch.jit.load(pinned, map_location="cpu").eval()
+    attribution = {}
     forced = _identical_inputs_against_rocm(ref, b_feats, dimgs[0], t(intr), t(extr), dmin, dmax, d_depth, d_dpm,
-                                            d_dbg[3][0]["view_weights"], _rel_stats)
+                                            d_dbg[3][0]["view_weights"], _rel_stats, cpu_ref=cpu_ref, attribution=attribution)
     free = {f"s{st}_it{it + 1}": _rel_stats(n(d), n(b_dpm[st][it])) for st in (3, 2, 1) for it, d in enumerate(d_dpm[st])}
     free["final"] = _rel_stats(n(d_depth), n(b_depth))
-    _report(test="identical_inputs_vs_reference_on_rocm", H=H, W=W, n_src=nsrc, rig=rig, forced=forced, free_running_on_the_reference_features=free)
+    _report(test="identical_inputs_vs_reference_on_rocm", H=H, W=W, n_src=nsrc, rig=rig, forced=forced, free_running_on_the_reference_features=free,
+            pixels_beyond_tolerance_attributed=attribution)
     # MEASURED (profiles/r05_rocm_parity.md): configs[2], general rig: max 7.1e-6 / 2.4e-4 / 4.1e-6 (stages 3 / 2 / 1), refinement 2.0e-7 --
     # every pixel inside the north star's 1e-3.  configs[4] (N=10, 6.3 M pixels): 1.8e-5 / 1.6e-3 / 1.1e-5, refinement 2.2e-7: ONE pixel
     # of the 393 K of stage 2 sits at 1.6e-3 (the reference's GPU kernels are not this engine's arithmetic operation for operation --
@@ -436,8 +548,16 @@ def test_identical_inputs_against_the_reference_on_rocm_cfg3_cfg5(H, W, nsrc, ri
         assert forced[k]["p99"] < 1e-5, (k, forced[k])
         if nsrc <= 7:
             assert forced[k]["max"] < 1e-3, (k, forced[k])
-        else:
-            assert forced[k]["frac_over_1e-3"] <= 1e-5 and forced[k]["max"] < 5e-3, (k, forced[k])
+        elif forced[k]["max"] >= 1e-3:
+            # configs[4]: a pixel beyond 1e-3 of the reference-on-ROCm is admitted ONLY where the reference's own CPU path, run on the
+            # very same tensors, agrees with THIS ENGINE (<= 1e-4) and disagrees with its own GPU path by the same amount: then the
+            # outlier is the reference's ROCm arithmetic at that pixel (ATen's reciprocal-multiply divisions, another fma order: one
+            # soft arg-max tipping among ten views), not this engine's (round 5 allowed "<= 1e-5 of the pixels, none beyond 5e-3"
+            # without looking at them: VERDICT r05 weak 2a)
+            assert k in attribution and attribution[k], (k, forced[k], "a pixel beyond 1e-3 that was not attributed")
+            for px in attribution[k]:
+                assert px["engine_vs_cpu"] < 1e-4 and px["rocm_vs_cpu"] > 0.5 * px["engine_vs_rocm"], (k, px)
+            assert forced[k]["frac_over_1e-3"] <= 1e-5, (k, forced[k])
     assert free["final"]["p99"] < (1e-4 if nsrc <= 7 else 2e-3), free["final"]  # the bulk; the tail is the cascade's amplification
 
 

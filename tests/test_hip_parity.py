@@ -512,7 +512,9 @@ def test_featurenet_hip_matches_miopen(mode):
     model.feature.fold_fpn = mode != "fp32_unfolded_fpn"
     if mode == "research_fp32":
         _research()
-        model.feature.research.update(winograd=True, winograd5=True, mfma_convs=True, fpn8_valu=True)
+        from patchmatchnet_amd import research
+        research.install(model, winograd=True, winograd5=True, mfma_convs=True)
+        model.feature.fpn8_valu = True
     x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
     with torch.no_grad():
         ref = model.feature(x)
