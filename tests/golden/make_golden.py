@@ -127,6 +127,7 @@ def dump_scene(path, model, n_views=6, H=1200, W=1600, scene_seed=0, noise_seed=
     for s in (1, 2, 3):
         for it, d in enumerate(dpm[s]):
             out[f"s{s}_it{it + 1}_depth_out"] = sub(t2n(d))
+    out["scene_thumb"], out["scene_sums"] = synth.scene_signature(imgs)  # host-tolerant form of scene_digest
     np.savez_compressed(path, **out)
     gt = depth_gt.numpy()
     err = np.abs(t2n(depth)[0, 0] - gt)
