@@ -278,6 +278,42 @@ def cpu_baseline(H, W, n_src, model_kw, thread_counts=(8, 32, 64)):
             "reference_measured_elsewhere": REFERENCE_CPU_MEASURED}
 
 
+def eval_end_to_end_leg(H, W, n_src, device, scans=6, views=49, timeout_s=300):
+    """eval.py --output_type depth in a FRESH process (what a user runs) on ``scans`` generated DTU-layout scans of ``views`` JPEGs at
+    the bench's size: decode, upload, per-scan feature cache, replayed forwards, download and map files included, model load excluded
+    (the figure eval.py prints itself).  VERDICT r05 item 8: the host half of the pipeline belongs on the driver-visible line."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import synth
+    base = tempfile.mkdtemp(prefix="pmn_bench_eval_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        data = os.path.join(base, "data")
+        t0 = time.perf_counter()
+        synth.write_scene_scan(data, "scan1", views, H, W, n_src=10, seed=0, device=device)
+        for k in range(1, scans):
+            shutil.copytree(os.path.join(data, "scan1"), os.path.join(data, "scan%d" % (k + 1)))
+        with open(os.path.join(data, "list.txt"), "w") as f:
+            f.write("".join("scan%d\n" % (k + 1) for k in range(scans)))
+        t_gen = time.perf_counter() - t0
+        cmd = [sys.executable, os.path.join(ROOT, "eval.py"), "--input_folder", data, "--output_folder", os.path.join(base, "out"),
+               "--checkpoint_path", os.path.join(ROOT, "tests", "golden", "params_000007.npz"), "--scan_list", os.path.join(data, "list.txt"),
+               "--num_views", str(n_src), "--file_format", ".pfm", "--output_type", "depth"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        m = re.search(r"depth stage: (\d+) samples in ([0-9.]+) s .*?-> ([0-9.]+) depth-maps/s", p.stdout)
+        if p.returncode != 0 or not m:
+            return {"error": (p.stderr or p.stdout)[-300:]}
+        return {"value": float(m.group(3)), "unit": "depth-maps/s", "samples": int(m.group(1)), "seconds": float(m.group(2)),
+                "what": f"eval.py --output_type depth --num_views {n_src} in a fresh process on {scans} generated scans of {views} {W}x{H} JPEGs "
+                        "(/dev/shm): decode, upload, per-scan feature cache (every view encoded once), replayed forwards, download and "
+                        ".pfm map files included; model load excluded", "scan_generation_seconds": round(t_gen, 1)}
+    except Exception as e:  # noqa: BLE001 -- an extra leg must never take the line down
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def self_launch(n_ranks):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one process per GPU, free rendezvous port on 127.0.0.1),
     rank 0 inherits stdout and prints the single JSON line; the exit code is the worst rank's."""
@@ -659,6 +695,8 @@ def main():
                                 if args.scene == "surface" else "rolled noise images (rounds 1-2)",
                        "parallelism": f"ref-view shards x{world}, all-gather of depth+confidence",
                        "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (GPU_MAX_HW_QUEUES unset: 4)"),
+                       "collective_stream": "RCCL's own stream, ordered after the slot streams through the launch stream (the closing all-gather "
+                                            "is issued there after main_stream.wait_stream(slot) for every slot)" if launched else None,
                        "ranks_seen": ranks_seen, "backend": dist.get_backend() if launched else "none (single process, no process group)",
                        "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 4),
                        "ms_per_step_rank_max": round(elapsed / args.steps * 1e3, 4),
@@ -718,6 +756,10 @@ def main():
                     ref_gpu["this_engine_over_reference"] = round(value / ref_gpu["value"], 2)
                     ref_gpu["this_engine_single_stream_over_reference"] = round((R / eager_elapsed) / ref_gpu["value"], 2)
                 line["reference_rocm"] = ref_gpu
+        if world == 1 and not args.no_cpu_baseline and not args.eager and (H, W, n_src) == (1200, 1600, 5):
+            samples.clear()  # (the pipeline leg brings its own inputs; give the child process the memory)
+            torch.cuda.empty_cache()
+            line["eval_end_to_end"] = eval_end_to_end_leg(H, W, n_src, device)
         print(json.dumps(line), flush=True)
     if launched:
         dist.barrier()

@@ -315,17 +315,40 @@ class CameraUploader:
         return out
 
 
+STRICT_DEPTH_RANGE = [False]  # --strict_depth_range 1
+
+
 def _check_depth_range(sample) -> None:
     """The kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite -- checked while the values are still host
-    numbers (before upload).  A degenerate range makes the reference divide by zero (models/patchmatch.py:656-657: inf / NaN maps);
-    the kernels' division sequence is IEEE for normal operands only, so such a sample is refused instead of producing NaN maps."""
+    numbers (before upload).  A degenerate range makes the reference divide by zero (models/patchmatch.py:656-657) and write inf / NaN
+    maps for that view while the run goes on (reference eval.py:56-82); the kernels' division sequence is IEEE for normal operands
+    only.  So such a sample is run on a stand-in range and its maps are REPLACED by NaN before they are written (``_degenerate``, read
+    by _write_maps): the run continues like the reference's, the view says loudly that it has no depth.  --strict_depth_range 1
+    raises instead (round 5's behaviour)."""
     lo, hi = (np.atleast_1d(np.asarray(sample[k], np.float64)) for k in ("depth_min", "depth_max"))
     bad = ~(np.isfinite(lo) & np.isfinite(hi) & (lo > 0.0) & (lo < hi))
-    if bad.any():
-        i = int(np.argmax(bad))
-        name = sample["filename"][i] if isinstance(sample["filename"], (list, tuple)) else sample["filename"]
-        raise P.PmnError("{}: depth range [{}, {}] is not 0 < depth_min < depth_max (finite): line 11 of the reference view's camera "
-                         "file must read 'depth_min depth_max'".format(name, lo[i], hi[i]))
+    if not bad.any():
+        return
+    i = int(np.argmax(bad))
+    name = sample["filename"][i] if isinstance(sample["filename"], (list, tuple)) else sample["filename"]
+    msg = ("{}: depth range [{}, {}] is not 0 < depth_min < depth_max (finite): line 11 of the reference view's camera file must read "
+           "'depth_min depth_max'".format(name, lo[i], hi[i]))
+    if STRICT_DEPTH_RANGE[0]:
+        raise P.PmnError(msg)
+    print("WARNING: " + msg + " -- this view's depth and confidence maps are written as NaN (the reference writes inf / NaN here)",
+          file=sys.stderr, flush=True)
+    for k, stand_in in (("depth_min", 1.0), ("depth_max", 2.0)):
+        v = sample[k]
+        if isinstance(v, torch.Tensor):
+            v = v.clone()
+            v.reshape(-1)[torch.from_numpy(bad)] = stand_in
+        elif isinstance(v, np.ndarray):
+            v = v.copy()
+            v.reshape(-1)[bad] = stand_in
+        else:
+            v = type(v)(stand_in)
+        sample[k] = v
+    sample["_degenerate"] = [bool(x) for x in bad]
 
 
 def _seed_sample(args, dataset, sample) -> None:
@@ -335,8 +358,11 @@ def _seed_sample(args, dataset, sample) -> None:
 
 
 def _write_maps(args, sample, depth, confidence, produced, writer):
+    degenerate = sample.get("_degenerate")
     for b, filename in enumerate(sample["filename"]):
         stacked = torch.stack((depth[b, 0], confidence[b]), 0)
+        if degenerate is not None and degenerate[b]:
+            stacked = torch.full_like(stacked, float("nan"))  # (see _check_depth_range)
         writer.submit(stacked, os.path.join(args.output_folder, filename.format("depth_est", args.file_format)),
                       os.path.join(args.output_folder, filename.format("confidence", args.file_format)))
         scan = filename.split("{}")[0].rstrip(os.sep)
@@ -453,7 +479,8 @@ def save_depth(args, rank, world, device, on_scan_done=None, scan_images=None):
             for i in indices:
                 s = dataset[i]
                 _check_depth_range(s)
-                yield {"intrinsics": torch.from_numpy(s["intrinsics"])[None], "extrinsics": torch.from_numpy(s["extrinsics"])[None],
+                yield {"_degenerate": s.get("_degenerate"),
+                       "intrinsics": torch.from_numpy(s["intrinsics"])[None], "extrinsics": torch.from_numpy(s["extrinsics"])[None],
                        "depth_min": torch.tensor([s["depth_min"]], dtype=torch.float64),
                        "depth_max": torch.tensor([s["depth_max"]], dtype=torch.float64), "ref_view": torch.tensor([s["ref_view"]]),
                        "view_ids": torch.from_numpy(s["view_ids"])[None], "scan": [s["scan"]], "light": [s["light"]],
@@ -883,6 +910,9 @@ def build_parser():
     p.add_argument("--decode_threads", type=int, default=-1,
                    help="JPEG decode threads per rank of the encode-once path (--feature_cache > 0, --stream_views 1); -1 = min(8, "
                         "this rank's share of the host's hardware threads)")
+    p.add_argument("--strict_depth_range", type=int, default=0,
+                   help="1: stop at the first camera file whose depth range is not 0 < depth_min < depth_max; 0 (default): warn, write NaN "
+                        "maps for that view and go on, as the reference's run goes on (it writes inf / NaN maps there)")
     p.add_argument("--sample_seed", type=int, default=-1,
                    help=">= 0: re-seed the device RNG per sample from (this value, scan, reference view) so the stage-3 random "
                         "hypotheses -- and with them every output byte -- do not depend on how samples are ordered or sharded "
@@ -919,6 +949,7 @@ def _scan_names(args):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    STRICT_DEPTH_RANGE[0] = bool(args.strict_depth_range)
     print("argv: ", sys.argv[1:] if argv is None else argv)
     print_args(args)
     if args.input_folder is None or not os.path.isdir(args.input_folder):

@@ -13,23 +13,25 @@
 //     (pixel, hypothesis) item and a wave covers 64/LPI consecutive pixels at the same hypothesis, so a wave-level
 //     corner load is one contiguous ~1 KB run of the source map whenever the homography is locally ~1 px/px.
 //   * a workgroup owns a tile of NPIX = 256/LPI consecutive pixels x all D hypotheses and alternates two roles:
-//       item role   thread <-> (pixel, a few hypotheses): projects the items and parks {texel offset, 4 corner
-//                   weights} in LDS (phase A: the projection is done once per item, not once per lane); later runs
-//                   the pointwise MLPs on its items (weights broadcast from LDS, each weight row reused for all the
-//                   thread's items) and stores cost[pixel][d] (hypothesis-last, what pmn_aggregate_regress gathers);
-//       lane role   LPI lanes <-> pixel: walk the pixel's hypotheses (phase B): LDS broadcast of the record,
-//                   4 x global_load_dwordx4, bilinear blend, product with the register-resident reference quad,
-//                   in-lane + one DPP step group reduction.  With known view weights the per-(pixel,group,d)
-//                   sums over views accumulate in REGISTERS of the owning lane (the d loop is fully unrolled over
-//                   the compile-time bound DT) and reach LDS once, for the hand-over to the item role; with
-//                   PixelwiseNet each view's tile goes through LDS to the item role, which evaluates the net,
-//                   takes the max over D with a 64-bit LDS atomic max (value bits | ~d -> first arg-max) and keeps
-//                   the weighted sums in its own registers.
+//       lane role   LPI lanes <-> pixel.  Lane lc projects hypotheses lc, lc + LPI, ... of ITS OWN pixel and keeps their tap records
+//                   {texel offset, 4 corner weights} in registers; the group then walks the pixel's hypotheses: DPP broadcast of
+//                   the record, 4 x global_load_dwordx4, bilinear blend, product with the register-resident reference quad,
+//                   in-lane + one DPP step group reduction.  No LDS and no barrier inside the loop (all three modes since round 6:
+//                   the FeatureWeightNet launches parked their records in LDS behind two barriers until then).  With known view
+//                   weights the per-(pixel,group,d) sums over views accumulate in REGISTERS of the owning lane (the d loop is
+//                   fully unrolled over the compile-time bound DT);
+//       item role   thread <-> (pixel, a few hypotheses): after ONE hand-over through LDS (similarity tile + barrier) runs the
+//                   pointwise MLPs on its items (weights broadcast from LDS, each weight row reused for all the thread's items)
+//                   and stores cost[pixel][d] (hypothesis-last, what pmn_aggregate_regress gathers) / the feature weights; with
+//                   PixelwiseNet each view's tile goes through LDS to the item role, which evaluates the net, takes the max over D
+//                   and keeps the weighted sums in its own registers (the cascade's stage-3 launch is the wave-private
+//                   pixelwise_wave_kernel below instead).
 //     The [C,D,h,w] warped volume and the per-view [G,D,h,w] similarity never touch HBM.
 //   * no MFMA: ~10 flop per gathered float, no dense contraction worth a matrix core (the MLPs are 16x8 / 8x16).
 #include <type_traits>
 
 #include "gather_common.hpp"
+
 
 // Broadcast `v` from lane SL of every aligned group of LPI lanes (SL compile-time): DPP quad_perm for 4-lane groups,
 // DPP row_newbcast for 16-lane groups (one VALU op, no LDS), ds_bpermute for 8-lane groups.
@@ -61,34 +63,7 @@ __device__ __forceinline__ const char* pmn_view_base(const GatherArgs& a, int v,
     return reinterpret_cast<const char*>(a.src) + ((size_t)(v * a.B + b) * hs * ws) * (C * 4);
 }
 
-// One (pixel, hypothesis) item of the lane role: returns this lane's group-correlation value (valid in the owner lane
-// of each group; with 8-channel groups both lanes of the pair hold it).
-
-template <int LPI, int LPG, int CG>
-__device__ __forceinline__ float gather_item(const float4* __restrict__ srcv, const float4 w4, const int off, const int ws,
-                                             const float4 refq) {
-    const float4* bp = srcv + (size_t)off * LPI;
-    const float4 t00 = bp[0];
-    const float4 t01 = bp[LPI];
-    const float4 t10 = bp[(size_t)ws * LPI];
-    const float4 t11 = bp[(size_t)ws * LPI + LPI];
-    // packed fp32 math (v_pk_mul/v_pk_fma: two channels per instruction); per channel the order of operations is the
-    // same as the scalar form: ((t00*w00 + t01*w01) + t10*w10) + t11*w11, then the dot product with the reference quad
-    const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
-    pmn_f2 lo = pmn_f2{t00.x, t00.y} * wa;
-    pmn_f2 hi = pmn_f2{t00.z, t00.w} * wa;
-    lo = __builtin_elementwise_fma(pmn_f2{t01.x, t01.y}, wb, lo);
-    hi = __builtin_elementwise_fma(pmn_f2{t01.z, t01.w}, wb, hi);
-    lo = __builtin_elementwise_fma(pmn_f2{t10.x, t10.y}, wc, lo);
-    hi = __builtin_elementwise_fma(pmn_f2{t10.z, t10.w}, wc, hi);
-    lo = __builtin_elementwise_fma(pmn_f2{t11.x, t11.y}, wd, lo);
-    hi = __builtin_elementwise_fma(pmn_f2{t11.z, t11.w}, wd, hi);
-    float s = fmaf(hi.y, refq.w, fmaf(hi.x, refq.z, fmaf(lo.y, refq.y, lo.x * refq.x)));
-    if (LPG == 2) s += pmn_pair_swap(s);
-    return s * (1.0f / CG);
-}
-
-// The same item in two halves, so a batch of items can have ALL its corner loads in flight before the first blend (left to
+// One (pixel, hypothesis) item of the lane role in two halves, so a batch of items can have ALL its corner loads in flight before the first blend (left to
 // itself hipcc schedules load -> wait -> blend item by item).  `sbase` is the wave-uniform base of the view's map (SGPR pair),
 // `bo` the 32-bit byte offset of this lane's channel quad of the north-west texel: the loads use the SGPR-base + VGPR-offset
 // form, east corner through the immediate offset field (no 64-bit VALU address arithmetic).
@@ -148,25 +123,22 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
     constexpr int NIT = DT / DSTEP;          // item role: hypotheses per thread
     constexpr int NI_MAX = (MODE == MODE_PIXELWISE) ? 2 : 4;  // PIXELWISE also keeps NIT*G running sums live
     constexpr int NI = NIT < NI_MAX ? NIT : NI_MAX;            // MLP evaluated for NI items at a time
-    constexpr int DCH = 32;                  // PIXELWISE / NEIGHBOR: hypotheses per phase-A/B round
     static_assert(CG == 4 || CG == 8, "group size must be 4 or 8 channels");
     static_assert(NIT >= 1, "DT must cover at least one hypothesis per item-role thread");
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int tile = pmn_xcd_tile(blockIdx.x, a.ntiles);
-    const int D = EXACT ? DT : a.D;
+    constexpr int DEXACT = (MODE == MODE_NEIGHBOR) ? (DT == 16 ? 9 : 17) : DT;  // FeatureWeightNet: EXACT = the reference's K = 9 / 17
+    const int D = EXACT ? DEXACT : a.D;
     const int N = a.N, h = a.h, w = a.w, hs = a.hs, ws = a.ws;
     const int hw = h * w;
     const int items = NPIX * D;
     const int SS = items + PAD;
     const int p0 = tile * NPIX;
-    const int rcap = (MODE == MODE_NEIGHBOR) ? NPIX * min(D, DCH) : 0;  // LDS tap records: FeatureWeightNet path only
 
     extern __shared__ float4 smem4[];
-    float4* recw = smem4;                                         // [rcap] corner weights
-    int* reco = reinterpret_cast<int*>(recw + rcap);              // [rcap] texel offsets
-    float* simt = reinterpret_cast<float*>(reco + rcap);          // [G][SS] similarity tile
+    float* simt = reinterpret_cast<float*>(smem4);                // [G][SS] similarity tile
     float* wlds_a = simt + ((G * SS + 3) & ~3);                   // MLP a weights (16-byte aligned)
     float* wlds_b = wlds_a + MLP_LDS_FLOATS;                      // MLP b weights           (PIXELWISE)
     unsigned long long* vwkey = reinterpret_cast<unsigned long long*>(wlds_b + MLP_LDS_FLOATS);  // [NPIX]
@@ -202,41 +174,6 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
     const bool owner = (lc % LPG) == 0;
     const int gB = lc / LPG;
 
-    // (the warp itself: pmn_make_pose / pmn_pose_position of pmn_common.hpp -- the reference's own IEEE chain)
-    using Pose = PmnPose;
-    auto make_pose = [&](const float* P) { return pmn_make_pose(P, (float)xA, (float)yA, h, w); };
-
-    // phase A for one view / hypothesis range [d_lo, d_hi): records land at rec_base + (d - d_lo)*NPIX + pixA
-    auto phase_a = [&](const Pose& q, int d_lo, int d_hi, int rec_base) {
-#pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            const int d = dA0 + j * DSTEP;
-            if (d < d_lo || d >= d_hi) continue;
-            // (plain scalars, not a PmnTaps temporary: hipcc kept the conditionally assigned struct in scratch)
-            float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            int off = 0;
-            if (okA) {
-                if (MODE == MODE_NEIGHBOR) {
-                    float ix, iy;
-                    const float ox = a.offsets[((size_t)b * 2 * D + 2 * d) * hw + pA];
-                    const float oy = a.offsets[((size_t)b * 2 * D + 2 * d + 1) * hw + pA];
-                    pmn_neighbor_position((float)xA, (float)yA, tab[2 * d], tab[2 * d + 1], ox, oy, h, w, ix, iy);
-                    const PmnTaps t = pmn_make_taps(ix, iy, hs, ws);
-                    w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
-                    off = t.off;
-                } else {
-                    float ix, iy;
-                    pmn_pose_position(q, a.depth[((size_t)b * D + d) * hw + pA], h, w, hs, ws, ix, iy);
-                    const PmnTaps t = pmn_make_taps(ix, iy, hs, ws);
-                    w4 = make_float4(t.w00, t.w01, t.w10, t.w11);
-                    off = t.off;
-                }
-            }
-            const int i = rec_base + (d - d_lo) * NPIX + pixA;
-            recw[i] = w4;
-            reco[i] = off;
-        }
-    };
 
     if (MODE == MODE_VIEWS) {
         // ================= known view weights: barrier-free streaming over the views ================================
@@ -365,11 +302,8 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
 
     for (int v = 0; v < N; ++v) {
         if (MODE == MODE_PIXELWISE && tid < NPIX) vwkey[tid] = 0ull;
-        Pose pose = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (MODE != MODE_NEIGHBOR) pose = make_pose(a.proj + ((size_t)b * N + v) * 16);
         const char* sbase = MODE == MODE_NEIGHBOR ? reinterpret_cast<const char*>(a.ref) + ((size_t)b * hs * ws) * (C * 4)
                                                   : pmn_view_base<C>(a, v, b, hs, ws);
-        const float4* srcv = reinterpret_cast<const float4*>(sbase) + lc;
         const unsigned lane_bytes = lc * 16u, row_bytes = (unsigned)ws * (C * 4);
         if constexpr (MODE == MODE_PIXELWISE) {
             // Lane role as in MODE_VIEWS: every lane projects RPL hypotheses of ITS OWN pixel, the records stay in registers and
@@ -437,39 +371,74 @@ __global__ __launch_bounds__(PMN_BLOCK, (MODE == MODE_PIXELWISE ? 3 : (MODE == M
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();  // this view's similarity tile is complete
-        } else
-        for (int dc0 = 0; dc0 < D; dc0 += DCH) {
-            const int dc1 = min(D, dc0 + DCH);
-            phase_a(pose, dc0, dc1, 0);
-            __syncthreads();
-            const float4* rw = recw + grp;
-            const int* ro = reco + grp;
-            // batches of NBP items: records from LDS + all corner loads first, then the blends (hipcc does not unroll this
-            // run-time-bounded loop by itself: one item = 4 loads in flight per wave, a latency chain per hypothesis)
-            constexpr int NBP = 2;
-            int d = dc0;
-            for (; d + NBP <= dc1; d += NBP) {
-                PmnCorners cn[NBP];
-                float4 wq[NBP];
+        } else if constexpr (MODE == MODE_NEIGHBOR) {
+            // FeatureWeightNet, round 6: the tap records stay in REGISTERS as in MODE_VIEWS -- lane lc of a pixel's lane group projects
+            // neighbours k = lc, lc + LPI, ... of ITS OWN pixel (get_grid's position, pmn_neighbor_position) and the record is broadcast
+            // inside the group by DPP when neighbour k is gathered.  Rounds 1-5 had the item role park the records in LDS behind two
+            // workgroup barriers (one before, one after the gather); what is left is the one barrier of the hand-over to the MLP.
+            constexpr int KD = EXACT ? (DT == 16 ? 9 : 17) : DT;  // EXACT here = "K is the reference's 9 (DT 16) or 17 (DT 32)"
+            constexpr int RPL = (KD + LPI - 1) / LPI;
+            float rw00[RPL], rw01[RPL], rw10[RPL], rw11[RPL];
+            int roff[RPL];
 #pragma unroll
-                for (int i = 0; i < NBP; ++i) {
-                    const int r = (d + i - dc0) * NPIX;
-                    wq[i] = pmn_settle4(rw[r]);  // LDS -> packed math (blend_corners): lesson 46
-                    cn[i] = load_corners<C>(sbase, (unsigned)ro[r] * (C * 4) + lane_bytes, row_bytes);
+            for (int j = 0; j < RPL; ++j) {
+                const int k = lc + j * LPI;
+                PmnTaps t;
+                t.off = 0;
+                t.w00 = t.w01 = t.w10 = t.w11 = 0.0f;
+                if (okB && k < (EXACT ? KD : D)) {
+                    float ix, iy;
+                    const float ox = a.offsets[((size_t)b * 2 * D + 2 * k) * hw + pB];
+                    const float oy = a.offsets[((size_t)b * 2 * D + 2 * k + 1) * hw + pB];
+                    pmn_neighbor_position((float)xB, (float)yB, tab[2 * k], tab[2 * k + 1], ox, oy, h, w, ix, iy);
+                    t = pmn_make_taps(ix, iy, hs, ws);
+                }
+                rw00[j] = t.w00; rw01[j] = t.w01; rw10[j] = t.w10; rw11[j] = t.w11;
+                roff[j] = t.off;
+            }
+            constexpr int NB = 2;
+#pragma unroll
+            for (int d0 = 0; d0 < KD; d0 += NB) {
+                PmnCorners cn[NB];
+                float4 wq[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (d < KD && (EXACT || d < D)) {
+                        float4 w4;
+                        int off;
+#define PMN_BCAST_CASE(SL)                                                    \
+    case SL:                                                                  \
+        w4.x = group_bcast_f<LPI, SL>(rw00[d / LPI]);                         \
+        w4.y = group_bcast_f<LPI, SL>(rw01[d / LPI]);                         \
+        w4.z = group_bcast_f<LPI, SL>(rw10[d / LPI]);                         \
+        w4.w = group_bcast_f<LPI, SL>(rw11[d / LPI]);                         \
+        off = group_bcast_i<LPI, SL>(roff[d / LPI]);                          \
+        break;
+                        switch (d % LPI) {
+                            PMN_BCAST_CASE(0) PMN_BCAST_CASE(1) PMN_BCAST_CASE(2) PMN_BCAST_CASE(3)
+                            PMN_BCAST_CASE(4) PMN_BCAST_CASE(5) PMN_BCAST_CASE(6) PMN_BCAST_CASE(7)
+                            PMN_BCAST_CASE(8) PMN_BCAST_CASE(9) PMN_BCAST_CASE(10) PMN_BCAST_CASE(11)
+                            PMN_BCAST_CASE(12) PMN_BCAST_CASE(13) PMN_BCAST_CASE(14) PMN_BCAST_CASE(15)
+                            default: w4 = make_float4(0.f, 0.f, 0.f, 0.f); off = 0; break;
+                        }
+#undef PMN_BCAST_CASE
+                        wq[i] = w4;
+                        cn[i] = load_corners<C>(sbase, (unsigned)off * (C * 4) + lane_bytes, row_bytes);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NBP; ++i) {
-                    const float s = blend_corners<LPG, CG>(cn[i], wq[i], refq);
-                    if (owner) simt[gB * SS + (d + i) * NPIX + grp] = s;
+                for (int i = 0; i < NB; ++i) {
+                    const int d = d0 + i;
+                    if (d < KD && (EXACT || d < D)) {
+                        const float s = blend_corners<LPG, CG>(cn[i], wq[i], refq);
+                        if (owner) simt[gB * SS + d * NPIX + grp] = s;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            for (; d < dc1; ++d) {
-                const float s = gather_item<LPI, LPG, CG>(srcv, pmn_settle4(rw[(d - dc0) * NPIX]), ro[(d - dc0) * NPIX], ws, refq);
-                if (owner) simt[gB * SS + d * NPIX + grp] = s;
-            }
-            __syncthreads();
+            __syncthreads();  // the similarity tile is complete
         }
         // item role: this view's similarities of my items (re-read from the LDS tile in chunks of NI to keep few live)
         if (MODE == MODE_NEIGHBOR) {
@@ -888,8 +857,7 @@ static int launch_gather_impl(GatherArgs& a, hipStream_t stream) {
     const int hw = a.h * a.w;
     a.ntiles = (hw + NPIX - 1) / NPIX;
     const int items = NPIX * a.D, SS = items + PAD;
-    const int rcap = (MODE == MODE_NEIGHBOR) ? NPIX * (a.D < 32 ? a.D : 32) : 0;
-    size_t lds = (size_t)rcap * 20 + (size_t)((G * SS + 3) & ~3) * 4 + 2 * MLP_LDS_FLOATS * 4 + NPIX * 8 +
+    size_t lds = (size_t)((G * SS + 3) & ~3) * 4 + 2 * MLP_LDS_FLOATS * 4 + NPIX * 8 +
                  2 * PMN_MAX_NEIGHBORS * 4;
     lds = (lds + 15) & ~(size_t)15;
     auto kern = gather_corr_kernel<C, G, MODE, DT, EXACT>;
@@ -907,6 +875,8 @@ template <int C, int G, int MODE, int DT>
 static int launch_gather(GatherArgs& a, hipStream_t stream) {
     if constexpr (MODE == MODE_VIEWS || MODE == MODE_PIXELWISE) {
         if (a.D == DT) return launch_gather_impl<C, G, MODE, DT, true>(a, stream);
+    } else {
+        if (a.D == (DT == 16 ? 9 : 17)) return launch_gather_impl<C, G, MODE, DT, true>(a, stream);  // the reference's neighbour counts
     }
     return launch_gather_impl<C, G, MODE, DT, false>(a, stream);
 }

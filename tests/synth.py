@@ -8,15 +8,16 @@ import numpy as np
 import torch
 
 
-def synthetic_cameras(n_views: int, H: int, W: int):
-    """DTU-like pinhole cameras orbiting the point (0,0,650): returns (intrinsics [1,N,3,3], extrinsics [1,N,4,4])."""
+def synthetic_cameras(n_views: int, H: int, W: int, step: float = 0.08):
+    """DTU-like pinhole cameras orbiting the point (0,0,650): returns (intrinsics [1,N,3,3], extrinsics [1,N,4,4]).  ``step`` = the
+    angle between neighbouring views in radians (view i sits at +- step * i)."""
     f = 2892.33 * W / 1600.0
     K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float64)
     intr = np.stack([K] * n_views).astype(np.float32)
     extr = []
     P = np.array([0.0, 0.0, 650.0])
     for i in range(n_views):
-        a = 0.0 if i == 0 else 0.08 * i * (1.0 if i % 2 else -1.0)
+        a = 0.0 if i == 0 else step * i * (1.0 if i % 2 else -1.0)
         R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
         E = np.eye(4)
         E[:3, :3] = R

@@ -207,7 +207,11 @@ def _scene_against_reference(P, fixture, gates):
     model, params, kw = _model(P)
     g = GU.load_npz(fixture)
     H, W, nv, st = int(g["H"]), int(g["W"]), int(g["n_views"]), int(g["stride"])
-    imgs, intr, extr, gt = synth.render_scene(nv, H, W, int(g["scene_seed"]))
+    # rendered on the device (float64; measured byte-identical to the CPU rendering the fixtures were made from, and seconds instead of
+    # minutes at these sizes); the signature check below admits isolated one-level differences should a host differ in its last bit
+    step = float(g["camera_step"]) if "camera_step" in g else 0.08
+    imgs, intr, extr, gt = synth.render_scene(nv, H, W, int(g["scene_seed"]), device=DEV, cameras=synth.synthetic_cameras(nv, H, W, step))
+    imgs, gt = [im.cpu() for im in imgs], gt.cpu()
     exact = synth.scene_digest(imgs) == str(g["scene_digest"])
     ok, note = (True, "byte-identical") if exact else synth.scene_matches(imgs, g["scene_thumb"], g["scene_sums"])
     assert ok, "this host renders a different scene than the golden was made on: " + note

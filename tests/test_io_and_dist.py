@@ -146,7 +146,7 @@ def test_camera_only_samples_and_view_dataset(tmp_path):
     assert item["view"] == views[0] and item["image"].shape == full["images"][0].shape
 
 
-def test_degenerate_depth_range_is_refused(tmp_path):
+def test_degenerate_depth_range_writes_nan_maps_or_is_refused(tmp_path):
     """The kernels' precondition (include/pmn_hip.h): 0 < depth_min < depth_max, finite.  eval.py refuses a sample with a degenerate
     range (the reference then divides by zero, models/patchmatch.py:656-657) while the values are host numbers; the dataset itself
     stays the reference's (it hands out whatever line 11 of the camera file holds, tests/test_reference_io.py)."""
@@ -165,8 +165,22 @@ def test_degenerate_depth_range_is_refused(tmp_path):
     ev._check_depth_range({"depth_min": torch.tensor([good["depth_min"]], dtype=torch.float64),  # the collated form
                            "depth_max": torch.tensor([good["depth_max"]], dtype=torch.float64), "filename": [good["filename"]]})
     for lo, hi in ((425.0, 425.0), (425.0, 2.5), (0.0, 935.0), (-1.0, 935.0), (425.0, float("inf")), (float("nan"), 935.0)):
-        with pytest.raises(Exception, match="depth range"):
-            ev._check_depth_range(dict(good, depth_min=np.float32(lo), depth_max=np.float32(hi)))
+        # default: the run goes on like the reference's -- the sample gets a stand-in range inside the kernels' domain and
+        # is marked, so that _write_maps writes NaN maps for it (the reference writes inf / NaN maps there)
+        s = dict(good, depth_min=np.float32(lo), depth_max=np.float32(hi))
+        ev._check_depth_range(s)
+        assert s["_degenerate"] == [True] and 0 < float(s["depth_min"]) < float(s["depth_max"])
+        c = {"depth_min": torch.tensor([425.0, lo], dtype=torch.float64), "depth_max": torch.tensor([935.0, hi], dtype=torch.float64),
+             "filename": ["a", "b"]}
+        ev._check_depth_range(c)  # the collated form, one good and one bad element
+        assert c["_degenerate"] == [False, True] and c["depth_min"].tolist()[0] == 425.0 and c["depth_max"].tolist() == [935.0, 2.0]
+        # --strict_depth_range 1: round 5's behaviour
+        ev.STRICT_DEPTH_RANGE[0] = True
+        try:
+            with pytest.raises(Exception, match="depth range"):
+                ev._check_depth_range(dict(good, depth_min=np.float32(lo), depth_max=np.float32(hi)))
+        finally:
+            ev.STRICT_DEPTH_RANGE[0] = False
 
 
 def _gather_worker(rank, world, port, H, W, ids, q):
