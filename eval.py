@@ -654,7 +654,7 @@ class ScanFuser:
                 continue  # drain: the launch thread will see the first error
             try:
                 with torch.no_grad():
-                    _fuse_scan(self.args, job, self.rank, self.world, self.device, stream, self.pool, self.io_pool, state)
+                    _fuse_scan_guarded(self.args, job, self.rank, self.world, self.device, stream, self.pool, self.io_pool, state)
             except BaseException as e:  # noqa: BLE001 -- handed to the launch thread
                 self.error = e
 
@@ -725,7 +725,24 @@ def filter_depth(args, scan, produced, rank, world, device, fuser=None, scan_ima
     else:
         with concurrent.futures.ThreadPoolExecutor(max_workers=max(getattr(args, "fuse_threads", 8), 2), thread_name_prefix="pmn-fuse") as pool, \
                 concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="pmn-ply") as io_pool:
-            _fuse_scan(args, job, rank, world, device, torch.cuda.current_stream(device), pool, io_pool, {})
+            _fuse_scan_guarded(args, job, rank, world, device, torch.cuda.current_stream(device), pool, io_pool, {})
+
+
+def _fuse_scan_guarded(args, job, rank, world, device, stream, pool, io_pool, state):
+    """_fuse_scan; with several ranks a failure leaves ``fused.ply.part<rank>.err`` next to the target so that rank 0, which polls for
+    the parts, stops at once instead of waiting for its timeout."""
+    try:
+        return _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state)
+    except BaseException as e:  # noqa: BLE001 -- re-raised
+        if world > 1:
+            try:
+                marker = os.path.join(args.output_folder, job["scan"], "fused.ply.part{}.err".format(rank))
+                os.makedirs(os.path.dirname(marker), exist_ok=True)
+                with open(marker, "w") as f:
+                    f.write("rank {}: {}: {}".format(rank, type(e).__name__, e))
+            except OSError:
+                pass
+        raise
 
 
 def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
@@ -761,6 +778,8 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
     with torch.cuda.device(device), torch.cuda.stream(stream):
         stream.wait_event(job["ready"])
         capacity = sum(sizes[ref][0] * sizes[ref][1] for ref, _ in my_pairs)
+        # (15 bytes per pixel of every reference view of the scan: 1.4 GB for 49 views of 1600x1200, 9 GB for 300 views of 1920x1080.
+        #  A buffer up to --fuse_buffer_mb stays with the worker for the next scan; a larger one is released when its scan is done.)
         packer = state.get("packer")
         if packer is None or packer.capacity < capacity or packer.view_counts.numel() < len(my_pairs):
             state.pop("packer", None)
@@ -781,6 +800,9 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
                 return self[ref]
 
         images = Images({ref: im for ref, im in job["images"].items() if im is not None})
+        for im in images.values():  # decoded on the copy stream, read here by pmn_pack_points: tell the caching allocator
+            if isinstance(im, torch.Tensor) and im.is_cuda:
+                im.record_stream(stream)
         # 1. every view's kernels, back to back: masks and points stay on the device, nothing waits for the host
         masks_dev = []
         for ref, m in fusion.fuse_views_packed(job["buf"], job["slot_of"], job["cams"], images, my_pairs, args.geo_pixel_thres,
@@ -835,6 +857,8 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
         finally:
             feeder.join()
             os.close(fd)
+    if 15 * capacity > (getattr(args, "fuse_buffer_mb", 4096) << 20):
+        state.pop("packer", None)  # (the tensors go back to the caching allocator once the last chunk has been downloaded: above)
     for ref, _ in my_pairs:
         photo, geo, final = fractions[ref]
         print("processing {}, ref-view{:0>3}, geo_mask:{:3f}, photo_mask:{:3f}, final_mask: {:3f}".format(
@@ -846,10 +870,13 @@ def _fuse_scan(args, job, rank, world, device, stream, pool, io_pool, state):
         os.replace(target, ply + ".part{}".format(rank))
         if rank == 0:
             parts = [ply + ".part{}".format(r) for r in range(world)]
-            deadline = time.time() + 3600.0
+            deadline = time.time() + float(getattr(args, "fuse_timeout", 600.0))
             while not all(os.path.exists(p) for p in parts):
+                failed = [p + ".err" for p in parts if os.path.exists(p + ".err")]
+                if failed:  # another rank's fusion stage raised: it left a marker instead of its part (see _fuse_scan_guarded)
+                    raise P.PmnError("{}: the fusion stage of another rank failed: {}".format(scan, open(failed[0]).read()[:500]))
                 if time.time() > deadline:
-                    raise P.PmnError("{}: the point lists of the other ranks never arrived ({})".format(scan, parts))
+                    raise P.PmnError("{}: the point lists of the other ranks never arrived within --fuse_timeout ({})".format(scan, parts))
                 time.sleep(0.005)
             n_points = sum(os.path.getsize(p) for p in parts) // 15
             with open(ply, "wb") as f:
@@ -919,6 +946,11 @@ def build_parser():
                         "(-1 = one RNG stream per process, like the reference)")
     p.add_argument("--writer_threads", type=int, default=4, help="threads writing depth / confidence maps behind the GPU")
     p.add_argument("--fuse_workers", type=int, default=2, help="--output_type both with --fuse_async 1: scans in the fusion stage at once")
+    p.add_argument("--fuse_buffer_mb", type=int, default=4096,
+                   help="the fusion stage's device record buffer (15 B per pixel of a scan's reference views) is kept between scans up to "
+                        "this size; a larger one is released after its scan")
+    p.add_argument("--fuse_timeout", type=float, default=600.0,
+                   help="several ranks: seconds rank 0 waits for the other ranks' point lists of a scan before it gives up")
     p.add_argument("--fuse_threads", type=int, default=-1,
                    help="threads of the fusion stage: mask PNG encoding, reference images the run did not decode itself, fused.ply chunks")
     p.add_argument("--fuse_async", type=int, default=1,
@@ -979,7 +1011,7 @@ def main(argv=None):
         # per-rank point lists are published as <scan>/fused.ply.part<rank> (see _fuse_scan): parts an interrupted earlier run left
         # behind must be gone before anybody starts waiting for this run's
         for scan in _scan_names(args):
-            for name in ("fused.ply.part{}".format(rank), "fused.ply.part{}.tmp".format(rank)):
+            for name in ("fused.ply.part{}".format(rank), "fused.ply.part{}.tmp".format(rank), "fused.ply.part{}.err".format(rank)):
                 stale = os.path.join(args.output_folder, scan, name)
                 if os.path.exists(stale):
                     os.remove(stale)
