@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 20
+#define PMN_ABI_VERSION 21
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -170,7 +170,7 @@ int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, f
  *     6.1e-5 <= |x| < 65504   (fp16's normal range: 22 significant bits per factor);
  * below 6.1e-5 `hi` is a subnormal (absolute error <= 3e-8 per factor -- irrelevant next to factors of normal size; an operand
  * tensor that is ENTIRELY below 1e-6 loses relative precision); at |x| >= 65504 `hi` becomes +-inf and the output is inf / NaN where
- * an fp32 convolution is finite.  The kernels do not check.  WEIGHTS are checked on the host when they are packed
+ * an fp32 convolution is finite.  The kernels do not check (opt-in: pmn_check_f16_domain, PMN_CHECK_F16_DOMAIN=1).  WEIGHTS are checked on the host when they are packed
  * (patchmatchnet_amd/params.py raises F16DomainError for a BatchNorm-folded weight outside (-65504, 65504), and the modules then use
  * the fp32 kernels pmn_stem / pmn_conv2d / pmn_refine_front + pmn_refine_tail and say so); ACTIVATIONS are the caller's contract:
  * images in [0, 1] (or any range below 6e4) and the reference checkpoint keep every intermediate below 1e2.
@@ -300,6 +300,13 @@ int pmn_pack_points(const unsigned char *final_mask, const float *xyz, const voi
  * With it a whole forward consists of launches of this library only, which is what makes it recordable as a launch plan. */
 int pmn_normalize_depth(const float *depth, const float *depth_min, const float *depth_max, int B, int n, float *out,
                         void *stream);
+
+/* ABI 21.  Opt-in range check for the fp16-split entry points (see "accepted magnitudes" above): ORs 1 into *flag (DEVICE int, zeroed by
+ * the caller) when some element of x[0..n) is not finite or has |x| >= 65504 -- the magnitude at which the split's `hi` half becomes inf.
+ * patchmatchnet_amd/ops.py runs it on the inputs of pmn_conv2d_f16s / pmn_offset_heads_f16s / pmn_stem_f16s / pmn_refine_fused when
+ * PMN_CHECK_F16_DOMAIN=1 and raises from ops.f16_domain_check(); intermediates that never leave a fused kernel (the stem's conv0 output,
+ * pmn_refine_fused's x16) are covered through the next layer's input. */
+int pmn_check_f16_domain(const float *x, long long n, int *flag, void *stream);
 
 /* ---- ABI 20: launch plans -------------------------------------------------------------------------------------------------------
  * A plan is a recorded list of kernel launches that pmn_plan_launch replays on a stream with plain hipLaunchKernel calls from C: the

@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -57,6 +57,7 @@ SIGNATURES = {
     "pmn_fuse_view": [_fp, ctypes.c_longlong, _i, _hp, _hp, _i, _fp, _i, _i, _f, _f, _i, _f, _fp, _fp, _fp, _ip, _s],
     "pmn_pack_points": [_fp, _fp, _fp, _i, _i, _i, _fp, ctypes.c_longlong, _fp, _ip, _fp, _s],
     "pmn_normalize_depth": [_fp, _fp, _fp, _i, _i, _fp, _s],
+    "pmn_check_f16_domain": [_fp, ctypes.c_longlong, _ip, _s],
     "pmn_plan_create": [ctypes.POINTER(ctypes.c_void_p)],
     "pmn_plan_begin": [_hp],
     "pmn_plan_end": [_hp],

@@ -259,3 +259,24 @@ extern "C" int pmn_normalize_depth(const float* depth, const float* depth_min, c
     PMN_CHECK_LAUNCH();
     return PMN_OK;
 }
+
+// ---- opt-in range check for the fp16-split entry points (include/pmn_hip.h, "fp16-split entry points: accepted magnitudes") -------------
+// Sets bit 0 of *flag when some |x| >= 65504 or x is not finite: `hi = fp16(x)` would then be inf and the convolution's output inf / NaN
+// where an fp32 convolution is finite.  Not part of any forward by default: patchmatchnet_amd/ops.py launches it on the inputs of the
+// _f16s entry points when PMN_CHECK_F16_DOMAIN=1 (the domain was a caller's contract nothing could detect).
+__global__ __launch_bounds__(PMN_BLOCK) void check_f16_domain_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long i = blockIdx.x * (long long)PMN_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * PMN_BLOCK) {
+        const float v = fabsf(x[i]);
+        bad |= !(v < 65504.0f);  // also true for NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int pmn_check_f16_domain(const float* x, long long n, int* flag, void* stream) {
+    if (!x || !flag || n < 1) return PMN_ERR_ARG;
+    const long long blocks = (n + PMN_BLOCK - 1) / PMN_BLOCK;
+    PMN_LAUNCH(check_f16_domain_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(PMN_BLOCK), 0, (hipStream_t)stream, x, n, flag);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}

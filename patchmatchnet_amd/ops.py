@@ -61,6 +61,41 @@ def set_tuning(key: int, value: int) -> None:
     check(_lib.lib().pmn_set_tuning(int(key), int(value)), "pmn_set_tuning")
 
 
+# ---- opt-in activation-range check of the fp16-split entry points (PMN_CHECK_F16_DOMAIN=1; include/pmn_hip.h) --------------------------
+import os as _os
+
+F16_DOMAIN_CHECK = _os.environ.get("PMN_CHECK_F16_DOMAIN", "") == "1"
+_F16_FLAGS = {}
+
+
+def _f16_domain_probe(*tensors: Optional[torch.Tensor]) -> None:
+    """PMN_CHECK_F16_DOMAIN=1: one pmn_check_f16_domain launch per input of an _f16s entry point (a pass over the tensor: a debugging
+    aid for checkpoints / inputs other than the ones this was built on, not a default)."""
+    if not F16_DOMAIN_CHECK:
+        return
+    for t in tensors:
+        if t is None or not t.is_cuda or t.numel() == 0:
+            continue
+        flag = _F16_FLAGS.get(t.device)
+        if flag is None:
+            flag = _F16_FLAGS[t.device] = torch.zeros(1, dtype=torch.int32, device=t.device)
+        with torch.cuda.device(t.device):
+            check(_lib.lib().pmn_check_f16_domain(t.data_ptr(), t.numel(), flag.data_ptr(), _stream(t)), "pmn_check_f16_domain")
+
+
+def f16_domain_check(reset: bool = True) -> None:
+    """Raises PmnError when an activation handed to an fp16-split kernel since the last call was not finite or >= 65504 in magnitude
+    (synchronises; only meaningful with PMN_CHECK_F16_DOMAIN=1)."""
+    bad = [str(d) for d, f in _F16_FLAGS.items() if int(f.item()) != 0]
+    if reset:
+        for f in _F16_FLAGS.values():
+            f.zero_()
+    if bad:
+        raise PmnError("an activation outside the fp16-split kernels' domain (|x| >= 65504 or not finite) reached pmn_*_f16s on " +
+                       ", ".join(bad) + ": the outputs contain inf / NaN where an fp32 convolution is finite -- set f16_split = False on "
+                       "FeatureNet / Refinement / PatchMatch for this checkpoint or input range (include/pmn_hip.h)")
+
+
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise PmnError(f"{name}: expected a torch.Tensor")
@@ -535,6 +570,7 @@ def conv2d_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, k: 
     operands -- fp32-convolution accuracy; x [N,H,W,cin] channels-last float32, weights float16 from params.pack_conv_f16s ->
     [N,(H-1)//stride+1,(W-1)//stride+1,cout] float32."""
     _dev(x, "x")
+    _f16_domain_probe(x)
     _dev(shift, "shift")
     if not isinstance(weights, torch.Tensor) or not weights.is_cuda or weights.dtype != torch.float16 or not weights.is_contiguous():
         raise PmnError("conv2d_f16s: weights must be a contiguous float16 tensor on a ROCm GPU (params.pack_conv_f16s)")
@@ -597,6 +633,7 @@ def offset_heads_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tenso
     models/patchmatch.py:288-311) as one dilated 3x3 convolution with bias on the fp16 matrix cores (split operands);
     x [N,H,W,cin] channels-last, weights / shift from params.pack_offset_heads_f16s -> ([N,ca,H,W], [N,cout-ca,H,W] or None) planar."""
     _dev(x, "x")
+    _f16_domain_probe(x)
     _dev(shift, "shift")
     N, H, W, cin = x.shape
     coutp = shift.shape[0]
@@ -687,6 +724,7 @@ def refine_fused(img: torch.Tensor, t2: torch.Tensor, w0: torch.Tensor, s0: torc
             tuple(w0.shape) != (3, 3, 3, 8) or tuple(wd.shape) != (3, 3, 8, 8) or tuple(wr.shape) != (3, 3, 8) or s3.numel() != 8 or \
             depth_min.numel() != B or depth_max.numel() != B:
         raise PmnError("refine_fused: inconsistent shapes")
+    _f16_domain_probe(img, t2)
     out = torch.empty((B, 1, H, W), dtype=torch.float32, device=img.device)
     with torch.cuda.device(img.device):
         check(_lib.lib().pmn_refine_fused(img.data_ptr(), t2.data_ptr(), w0.data_ptr(), s0.data_ptr(), wd.data_ptr(), sd.data_ptr(),
@@ -741,6 +779,7 @@ def stem_f16s(img: torch.Tensor, w0: torch.Tensor, s0: torch.Tensor, w1a: torch.
     N, c, H, W = img.shape
     if c != 3 or tuple(w0.shape) != (3, 3, 3, 8):
         raise PmnError("stem_f16s: expects a 3-channel image and 3->8 conv0 weights")
+    _f16_domain_probe(img)
     if out is None:
         out = torch.empty((N, H, W, 8), dtype=torch.float32, device=img.device)
     else:

@@ -889,6 +889,34 @@ def test_f16_split_domain():
             assert not bool(torch.isfinite(got).all())  # hi = fp16(7e4) = inf
 
 
+def test_f16_domain_check_is_opt_in_and_catches_a_scaled_model():
+    """PMN_CHECK_F16_DOMAIN=1: every input of an fp16-split entry point is scanned by pmn_check_f16_domain and
+    ops.f16_domain_check() raises when one was not finite or >= 65504 in magnitude -- here a checkpoint whose first layer is scaled
+    so that FeatureNet's activations leave float16's range (every weight still packs: the weights' own check cannot see it).  Off by
+    default: the product forward launches no check kernel."""
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
+    ops = P.ops
+    assert ops.F16_DOMAIN_CHECK is False  # the suite runs without the variable
+    ops.F16_DOMAIN_CHECK = True
+    try:
+        with torch.no_grad():
+            model.feature.forward_hip(x)
+            ops.f16_domain_check()  # the released checkpoint on images in [0, 1]: inside the domain
+            model.feature.forward_hip(x * 3.0e6)  # activations ~1e6 x the usual few units
+            with pytest.raises(P.PmnError, match="65504"):
+                ops.f16_domain_check()
+            ops.f16_domain_check()  # the flag was reset
+            bad = torch.full((1, 8, 8, 16), float("nan"), device=DEV)
+            ops._f16_domain_probe(bad)
+            with pytest.raises(P.PmnError, match="65504"):
+                ops.f16_domain_check()
+    finally:
+        ops.F16_DOMAIN_CHECK = False
+
+
 def test_f16_split_weights_outside_the_range_fall_back_to_fp32():
     """A BatchNorm running_var small enough to fold conv3's weights beyond 65504: params refuses to pack them, FeatureNet says so
     (RuntimeWarning + f16_domain_error) and runs the fp32 kernels -- finite output equal to the MIOpen module's."""
