@@ -260,14 +260,16 @@ def test_cfg3_scene_end_to_end_against_the_reference_itself():
     own CPU<->ROCm distance is 5.4e-4 of the pixels, profiles/r05_rocm_parity.md) at 1.5x what this configuration measures."""
     P = _gpu()
     # measured (profiles/r06_parity_report.jsonl): 2.6e-4 of the final-depth pixels beyond 1e-3, max 7.2e-3, p99 2.0e-6
-    _scene_against_reference(P, "cfg3_scene.npz", dict(frac=3.9e-4, max=1.1e-2, p999=3e-3))
+    _scene_against_reference(P, "cfg3_scene.npz", dict(frac=3.9e-4, max=1.1e-2, p999=5e-4))
 
 
 def test_cfg5_scene_end_to_end_against_the_reference_itself():
     """BASELINE configs[4] (ETH3D shape: 3072x2048, N=10, one GPU's share), the same way (tests/golden/cfg5_scene.npz, every fourth
     pixel in both directions)."""
     P = _gpu()
-    _scene_against_reference(P, "cfg5_scene.npz", dict(frac=2.5e-4, max=2.5e-2, p999=3e-4))
+    # measured (profiles/r06_parity_report.jsonl): 7.6e-6 of the final-depth pixels beyond 1e-3 (4.1e-5 at stage 2, iteration 2), max
+    # 2.1e-3, p99.9 5.1e-6 -- on a rig of 0.04 rad per view (see make_golden.py: the 0.08 rig does not render identically on two hosts)
+    _scene_against_reference(P, "cfg5_scene.npz", dict(frac=7e-5, max=3.2e-3, p999=1e-5))
 
 
 def test_cfg2_scene_end_to_end_against_the_reference_itself():
