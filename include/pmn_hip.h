@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PMN_ABI_VERSION 21
+#define PMN_ABI_VERSION 22
 #define PMN_MLP_FLOATS 340
 #define PMN_MAX_DEPTH 64
 #define PMN_MAX_NEIGHBORS 17
@@ -186,6 +186,15 @@ int pmn_conv2d_mfma(const float *in, const float *weights, const float *shift, f
  * [N,(H-1)/stride+1,(W-1)/stride+1,cout] float32 (padding k/2). */
 int pmn_conv2d_f16s(const float *in, const void *weights, const float *shift, float *out, int N, int H, int W, int cin, int cout,
                     int k, int stride, int relu, void *stream);
+
+/* ABI 22.  Two consecutive 3x3 / stride-1 / 16 -> 16 ConvBnReLU layers in ONE launch (FeatureNet conv3 + conv4 at half resolution,
+ * reference models/net.py:21-22, 52): the 184 MB intermediate map of six 1600x1200 views never goes to HBM (the first layer is
+ * evaluated on each 14 x 14 tile's 16 x 16 halo region and kept in LDS as split fp16 planes).  in / out [N,H,W,16] channels-last
+ * float32; weights_* / shift_* exactly as pmn_conv2d_f16s takes them for a (k 3, stride 1, 16 -> 16) layer; relu applies to both
+ * layers.  Bit-identical to two pmn_conv2d_f16s calls.  channels != 16: PMN_ERR_SHAPE (the other layer pairs of FeatureNet do not
+ * pay: profiles/r06_conv_fusion_bound.log). */
+int pmn_conv2d_f16s_pair(const float *in, const void *weights_a, const float *shift_a, const void *weights_b, const float *shift_b,
+                         float *out, int N, int H, int W, int channels, int relu, void *stream);
 
 /* The offset heads of one PatchMatch stage -- propa_conv rows first, then eval_conv (reference models/patchmatch.py:288-311, :467, :471) --
  * as ONE dilated 3x3 convolution with bias on the fp16 matrix cores with split operands (see pmn_conv2d_f16s), planar outputs.

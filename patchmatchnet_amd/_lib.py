@@ -13,7 +13,7 @@ from typing import Optional
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpmn_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 MLP_FLOATS = 340
 MAX_DEPTH = 64
 MAX_NEIGHBORS = 17
@@ -44,6 +44,7 @@ SIGNATURES = {
     "pmn_fpn_level": [_fp] * 6 + [_i] * 6 + [_s],
     "pmn_conv2d_f16s": [_fp] * 4 + [_i] * 8 + [_s],
     "pmn_offset_heads_f16s": [_fp] * 5 + [_i] * 7 + [_s],
+    "pmn_conv2d_f16s_pair": [_fp] * 6 + [_i] * 5 + [_s],
     "pmn_refine_front": [_fp] * 7 + [_i] * 3 + [_s],
     "pmn_refine_tail": [_fp] * 8 + [_i] * 3 + [_s],
     "pmn_refine_fused": [_fp] * 13 + [_i] * 3 + [_s],

@@ -309,6 +309,180 @@ extern "C" int pmn_conv2d_f16s(const float* in, const void* weights, const float
 }
 
 
+// =================================================================================================================================
+// TWO consecutive 3x3 / stride-1 / 16 -> 16 ConvBnReLU layers in one launch (FeatureNet conv3 + conv4 at half resolution, reference
+// models/net.py:21-22, 52) -- round 6.
+//
+// Why these two.  Ablation builds of the kernel above (stores predicated off / patch loads from an L2-resident window:
+// profiles/r06_conv_fusion_bound.log) price what the intermediate map's trip through HBM costs per layer pair: 8 us for conv6+conv7,
+// 9 us for conv9+conv10 (those layers are bound by operand delivery, as their tile A/Bs said) -- and 60-70 us for conv3+conv4, which
+// move 184 MB out and back in at half resolution and are HBM-bound.  So the pair that is fused is this one, not the ones the reviews
+// of rounds 4 and 5 asked for.
+//
+// Mapping.  Workgroup = 14 x 14 output pixels.  (1) the 18 x 18 input patch is staged as hi / lo fp16 planes exactly as above.
+// (2) layer A on the 16 x 16 region the second layer reads (one 16-pixel M-tile per row, four rows per wave), operand roles swapped
+// as in the single-layer kernel: same k order, same MFMA sequence per accumulator, same epilogue expression, so the region holds the
+// BITS pmn_conv2d_f16s would have written; positions outside the image are ZERO (layer B pads layer A's output, not its input).
+// (3) after a barrier the region is split into hi / lo planes IN PLACE of the input patch (same conversion as the staging code).
+// (4) layer B on the 14 x 14 tile from those planes, epilogue and channels-last stores as above.  Halo recompute: layer A does
+// 256 / 196 = 1.31x the MFMAs of the unfused layer and layer B runs 16-wide tiles for 14 valid columns; the matrix pipe has that slack
+// (these layers ran at 20 % of it).  HBM: 1.65x the input once + 1x the output instead of 2 x (1.27 + 1): 498 instead of 835 MB per six
+// 1600x1200 views.  Measured: 160 us instead of 92 + 91 (same box, scripts/call_ab.py; 4 / 5 / 6 / 8 waves per SIMD: 160 / 163 / 162 /
+// 189) -- the HBM time alone would be ~100 us: a workgroup's four phases run one after the other behind three barriers and four to
+// six workgroups per CU do not hide that; a wider tile or a producer / consumer wave split is what is left to try.
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_f16s_pair16_kernel(const float* __restrict__ in, const f16x8* __restrict__ wA,
+                                                                   const float* __restrict__ shiftA, const f16x8* __restrict__ wBq,
+                                                                   const float* __restrict__ shiftB, float* __restrict__ out,
+                                                                   const F16sArgs a) {
+    constexpr int C = 16, CCP = 16, NCB = 2, NQ = 18, KSTEPS = 5, TO = 14, RA = 16, PI = 18;
+    constexpr int PLANE = PI * PI * CCP;  // halves per plane (layer A's 16 x 16 region re-uses the same two planes at pitch RA)
+    extern __shared__ float4 f16s_pair_lds4[];
+    _Float16* Phi = reinterpret_cast<_Float16*>(f16s_pair_lds4);
+    _Float16* Plo = Phi + PLANE;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, kb = lane >> 4;
+    const int tiles_x = (a.W + TO - 1) / TO, tiles_y = (a.H + TO - 1) / TO;
+    const int bt = pmn_xcd_tile(blockIdx.x, a.N * tiles_x * tiles_y);
+    const int n = bt / (tiles_x * tiles_y), tr = bt - n * tiles_x * tiles_y;
+    const int oy0 = (tr / tiles_x) * TO, ox0 = (tr % tiles_x) * TO;
+
+    // ---- (1) input patch, origin (oy0 - 2, ox0 - 2): 324 pixels x 4 channel quads, all of a thread's loads in flight before the split
+    {
+        constexpr int QP = C / 4, TOT = PI * PI * QP, NL = (TOT + 255) / 256;
+        const float* src = in + (size_t)n * a.H * a.W * C;
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256, pix = idx / QP, q = idx - pix * QP;
+            const int py = pix / PI, px = pix - py * PI, gy = oy0 - 2 + py, gx = ox0 - 2 + px;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOT && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                v[k] = *reinterpret_cast<const float4*>(src + ((unsigned)(gy * a.W + gx) * C + 4 * q));
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256, pix = idx / QP, q = idx - pix * QP;
+            if (idx < TOT) {
+                const f32x2_t x01 = {v[k].x, v[k].y}, x23 = {v[k].z, v[k].w};
+                const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);  // RNE
+                const f16x2_t l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+                const f16x2_t l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+                const f16x4 hi = {h01[0], h01[1], h23[0], h23[1]}, lo = {l01[0], l01[1], l23[0], l23[1]};
+                *reinterpret_cast<f16x4*>(Phi + pix * CCP + 4 * q) = hi;
+                *reinterpret_cast<f16x4*>(Plo + pix * CCP + 4 * q) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // one 3x3 / 16 -> 16 layer over four rows of 16 pixels per wave from planes of row pitch `pitch` pixels: the k loop of
+    // conv_f16s_kernel<16, 16, 3, 1, 16, 16, 4, ..., SWAP = true> (B operands one k-step ahead in registers)
+    f32x4_t accM[4], accL[4];
+    auto layer = [&](const f16x8* __restrict__ wq, const int pitch) {
+        const f16x8* bl = wq + lane;
+        f16x8 bq[2][2];
+        bq[0][0] = bl[0];
+        bq[0][1] = bl[64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            accM[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            accL[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            const int sidx = ks + 1 < KSTEPS ? ks + 1 : KSTEPS - 1;
+            bq[nxt][0] = bl[(size_t)(sidx * 2 + 0) * 64];
+            bq[nxt][1] = bl[(size_t)(sidx * 2 + 1) * 64];
+            int q = 4 * ks + kb;
+            if (4 * ks + 3 >= NQ) q = q < NQ - 1 ? q : NQ - 1;
+            const int tap = q / NCB, cb = q - tap * NCB;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const _Float16* pa = Phi + ((wave * 4 + dy) * pitch + li + dx) * CCP + cb * 8;
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(pa + t * pitch * CCP);
+                al[t] = *reinterpret_cast<const f16x8*>(pa + t * pitch * CCP + PLANE);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][0], ah[t], accM[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][1], ah[t], accL[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accL[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[cur][0], al[t], accL[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- (2) layer A on the 16 x 16 region, origin (oy0 - 1, ox0 - 1): lane (li, kb) ends up with channels 4 kb .. + 3 of column li
+    layer(wA, PI);
+    f16x4 rh[4], rl[4];
+    {
+        const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shiftA + 4 * kb);
+        const int gx = ox0 - 1 + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int gy = oy0 - 1 + wave * 4 + t;
+            f32x4_t v = accM[t] + accL[t] * (1.0f / PMN_F16S_LO_SCALE) + sh;
+            if (a.relu) v = __builtin_elementwise_max(v, f32x4_t{0.f, 0.f, 0.f, 0.f});
+            if (!((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)) v = f32x4_t{0.f, 0.f, 0.f, 0.f};  // layer B's zero padding
+            const f32x2_t x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
+            const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);
+            const f16x2_t l01 = __builtin_convertvector((x01 - __builtin_convertvector(h01, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+            const f16x2_t l23 = __builtin_convertvector((x23 - __builtin_convertvector(h23, f32x2_t)) * PMN_F16S_LO_SCALE, f16x2_t);
+            rh[t] = f16x4{h01[0], h01[1], h23[0], h23[1]};
+            rl[t] = f16x4{l01[0], l01[1], l23[0], l23[1]};
+        }
+    }
+    __syncthreads();  // every wave is done reading the input patch: the region takes its place
+    // ---- (3) the region as hi / lo planes [16 rows][16 px][16 halves]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int pix = (wave * 4 + t) * RA + li;
+        *reinterpret_cast<f16x4*>(Phi + pix * CCP + 4 * kb) = rh[t];
+        *reinterpret_cast<f16x4*>(Plo + pix * CCP + 4 * kb) = rl[t];
+    }
+    __syncthreads();
+
+    // ---- (4) layer B on the 14 x 14 tile (rows / columns 14, 15 of the 16-wide tiles read past the region: computed, never stored)
+    layer(wBq, RA);
+    {
+        const int ox = ox0 + li;
+        if (li < TO && ox < a.W) {
+            const f32x4_t sh = *reinterpret_cast<const f32x4_t*>(shiftB + 4 * kb);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = wave * 4 + t, oy = oy0 + r;
+                if (r < TO && oy < a.H) {
+                    f32x4_t v = accM[t] + accL[t] * (1.0f / PMN_F16S_LO_SCALE) + sh;
+                    if (a.relu) v = __builtin_elementwise_max(v, f32x4_t{0.f, 0.f, 0.f, 0.f});
+                    *reinterpret_cast<f32x4_t*>(out + (((size_t)n * a.H + oy) * a.W + ox) * C + 4 * kb) = v;
+                }
+            }
+        }
+    }
+}
+
+// in [N,H,W,16] channels-last float32 -> out [N,H,W,16] = relu(convB(relu(convA(in)) ...)): weights_a / weights_b, shift_a / shift_b as
+// pmn_conv2d_f16s takes them for a (3, 1, 16, 16) layer (params.pack_conv_f16s).  Bit-identical to two pmn_conv2d_f16s calls.
+extern "C" int pmn_conv2d_f16s_pair(const float* in, const void* weights_a, const float* shift_a, const void* weights_b,
+                                    const float* shift_b, float* out, int N, int H, int W, int channels, int relu, void* stream) {
+    if (!in || !weights_a || !shift_a || !weights_b || !shift_b || !out || N < 1 || H < 1 || W < 1) return PMN_ERR_ARG;
+    if (channels != 16) return PMN_ERR_SHAPE;
+    if ((size_t)H * W * 16 >= ((size_t)1 << 30)) return PMN_ERR_SHAPE;
+    F16sArgs a;
+    a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.relu = relu;
+    a.cout = 16; a.ca = 16; a.out_b = nullptr;
+    const size_t lds = (size_t)2 * 18 * 18 * 16 * sizeof(_Float16);
+    const int blocks = N * ((W + 13) / 14) * ((H + 13) / 14);
+    PMN_LAUNCH(conv_f16s_pair16_kernel<4>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, in, reinterpret_cast<const f16x8*>(weights_a),
+               shift_a, reinterpret_cast<const f16x8*>(weights_b), shift_b, out, a);
+    PMN_CHECK_LAUNCH();
+    return PMN_OK;
+}
+
+
 // The offset heads of one PatchMatch stage (propa_conv rows first, then eval_conv: reference models/patchmatch.py:288-311) as ONE dilated
 // 3x3 convolution with bias on the fp16 matrix cores (split operands), planar outputs.  in [N,H,W,cin] channels-last; weights DEVICE
 // fp16 [cin/16][k-steps][coutp/16][2][64][8] (params.pack_conv_f16s_general, rows padded with zeros to coutp = a multiple of 16); shift

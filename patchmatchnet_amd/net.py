@@ -53,6 +53,8 @@ class FeatureNet(nn.Module):
         # verification switch, not a performance choice: False = the FPN head layer by layer in the reference's order instead of the
         # host-composed 1x1 convolutions (an algebraic re-association)
         self.fold_fpn = True
+        # conv3 + conv4 as ONE launch (pmn_conv2d_f16s_pair, bit-identical to the two launches); False = one launch per layer
+        self.fuse_conv34 = True
         # verification switch (test hook): the FPN's 1/8 level through the VALU kernel (pmn_fpn_level) instead of the fp32 matrix cores
         self.fpn8_valu = False
         # None in the product.  patchmatchnet_amd/research.py (PMN_EXPERIMENTAL=1 only) installs a callable (layer index, input) ->
@@ -134,7 +136,13 @@ class FeatureNet(nn.Module):
         for i, (k, s, p) in enumerate(self._SPEC):
             if i < 2:
                 continue
-            if self.f16_split and f"conv{i}_f16s" in pk:  # fp16 matrix cores, split operands
+            if i == 4 and self.f16_split and self.fuse_conv34 and "conv3_f16s" in pk and "conv4_f16s" in pk:
+                continue  # (done with conv3 below)
+            if i == 3 and self.f16_split and self.fuse_conv34 and "conv3_f16s" in pk and "conv4_f16s" in pk:
+                # conv3 + conv4 in one launch: the half-resolution intermediate (184 MB for six 1600x1200 views) stays in LDS (round 6)
+                t = ops.conv2d_f16s_pair(t, *pk["conv3_f16s"], *pk["conv4_f16s"], relu=True)
+                feats[4] = t
+            elif self.f16_split and f"conv{i}_f16s" in pk:  # fp16 matrix cores, split operands
                 t = ops.conv2d_f16s(t, *pk[f"conv{i}_f16s"], k, s, relu=True)
             elif self.layer_hook is not None and (hooked := self.layer_hook(i, t)) is not None:  # research build only
                 t = hooked

@@ -589,6 +589,28 @@ def conv2d_f16s(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, k: 
     return out
 
 
+def conv2d_f16s_pair(x: torch.Tensor, weights_a: torch.Tensor, shift_a: torch.Tensor, weights_b: torch.Tensor, shift_b: torch.Tensor,
+                     relu: bool = True) -> torch.Tensor:
+    """pmn_conv2d_f16s_pair: two consecutive 3x3 / stride-1 / 16 -> 16 ConvBnReLU layers in one launch (FeatureNet conv3 + conv4), the
+    intermediate map kept in LDS; x [N,H,W,16] channels-last float32, (weights, shift) pairs from params.pack_conv_f16s.  Bit-identical
+    to conv2d_f16s(conv2d_f16s(x, a...), b...)."""
+    _dev(x, "x")
+    _f16_domain_probe(x)
+    N, H, W, C = x.shape
+    for w_, s_ in ((weights_a, shift_a), (weights_b, shift_b)):
+        _dev(s_, "shift")
+        if not isinstance(w_, torch.Tensor) or not w_.is_cuda or w_.dtype != torch.float16 or not w_.is_contiguous() or \
+                tuple(w_.shape) != (1, 5, 1, 2, 64, 8) or s_.numel() != 16:
+            raise PmnError("conv2d_f16s_pair: weights must be params.pack_conv_f16s of a (3, 1, 16, 16) layer on a ROCm GPU")
+    if C != 16:
+        raise PmnError("conv2d_f16s_pair: 16-channel layers only")
+    out = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pmn_conv2d_f16s_pair(x.data_ptr(), weights_a.data_ptr(), shift_a.data_ptr(), weights_b.data_ptr(), shift_b.data_ptr(),
+                                              out.data_ptr(), N, H, W, 16, 1 if relu else 0, _stream(x)), "pmn_conv2d_f16s_pair")
+    return out
+
+
 def pointwise_split_mfma(x: torch.Tensor, weights: torch.Tensor, shift: torch.Tensor, cout: int, ca: int):
     """pmn_conv2d_mfma, 1x1 form: out = x @ W + shift on the matrix cores with the output channels split between two
     channels-last tensors (the 1/8-resolution level of the folded FPN head); x [N,H,W,64], weights from

@@ -889,6 +889,44 @@ def test_f16_split_domain():
             assert not bool(torch.isfinite(got).all())  # hi = fp16(7e4) = inf
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 37, 53), (1, 28, 14), (3, 14, 45), (1, 600, 800)])
+def test_conv2d_f16s_pair_is_two_single_layers_bit_for_bit(N, H, W):
+    """pmn_conv2d_f16s_pair (FeatureNet conv3 + conv4 in one launch, the intermediate map in LDS; round 6) against two
+    pmn_conv2d_f16s launches: the same bits at ragged sizes (tiles of 14 x 14 cut by the image border: the second layer pads the first
+    layer's OUTPUT with zeros, not its input), several images, and the benchmark's half resolution."""
+    P = _gpu()
+    from patchmatchnet_amd import params as PP
+    gen = torch.Generator().manual_seed(11)
+    packs = []
+    for _ in range(2):
+        wt = 0.15 * torch.randn(16, 16, 3, 3, generator=gen)
+        bn = (torch.rand(16, generator=gen) + 0.5, 0.1 * torch.randn(16, generator=gen), 0.1 * torch.randn(16, generator=gen),
+              torch.rand(16, generator=gen) + 0.5)
+        w, sh = PP.pack_conv_f16s(wt, bn=bn)
+        packs.append((torch.from_numpy(w).to(DEV), torch.from_numpy(sh).to(DEV)))
+    x = torch.randn(N, H, W, 16, generator=gen).to(DEV)
+    want = P.ops.conv2d_f16s(P.ops.conv2d_f16s(x, *packs[0], 3, 1, relu=True), *packs[1], 3, 1, relu=True)
+    got = P.ops.conv2d_f16s_pair(x, *packs[0], *packs[1], relu=True)
+    assert got.shape == want.shape and torch.equal(got, want), float((got - want).abs().max())
+    want = P.ops.conv2d_f16s(P.ops.conv2d_f16s(x, *packs[0], 3, 1, relu=False), *packs[1], 3, 1, relu=False)
+    got = P.ops.conv2d_f16s_pair(x, *packs[0], *packs[1], relu=False)
+    assert torch.equal(got, want)
+
+
+def test_featurenet_fused_conv34_is_the_unfused_network():
+    P = _gpu()
+    g, params, kw = GU.load_case("default")
+    model = _model(P, params, kw)
+    x = torch.cat([t(g[f"image_{v}"]) for v in range(int(g["n_views"]))], 0)
+    with torch.no_grad():
+        assert model.feature.fuse_conv34
+        a = model.feature.forward_hip(x)
+        model.feature.fuse_conv34 = False
+        b = model.feature.forward_hip(x)
+    for s in (1, 2, 3):
+        assert torch.equal(a[s], b[s]), s
+
+
 def test_f16_domain_check_is_opt_in_and_catches_a_scaled_model():
     """PMN_CHECK_F16_DOMAIN=1: every input of an fp16-split entry point is scanned by pmn_check_f16_domain and
     ops.f16_domain_check() raises when one was not finite or >= 65504 in magnitude -- here a checkpoint whose first layer is scaled

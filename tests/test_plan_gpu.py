@@ -60,7 +60,7 @@ def test_a_plan_recorded_on_one_sample_replays_any_other():
         assert slot.captures == 1 and slot.replays == 4
         handle = next(iter(slot.cache.values()))[0]
         names = handle.kernel_names()
-        assert handle.count == len(names) >= 40, handle.count
+        assert handle.count == len(names) >= 35, handle.count
         # the whole forward is in the plan: FeatureNet's stem, the five warp+correlate launches, Refinement, the confidence epilogue
         assert any("stem_f16s_kernel" in n for n in names) and any("refine_fused_kernel" in n for n in names)
         assert sum("gather_corr_kernel" in n or "pixelwise_wave_kernel" in n for n in names) == 5 + 3  # + FeatureWeightNet per stage
