@@ -39,7 +39,7 @@ model = model.to(dev).eval()
 samples = bench.make_samples(2, args.views + 1, args.height, args.width, dev, 0)
 noise = torch.rand((1, 48, args.height // 8, args.width // 8), device=dev)
 
-NAMES = ["stem_f16s_views", "stem_f16s", "stem", "conv2d_f16s", "pointwise_split_mfma", "fpn_level", "stage_projections", "offset_heads_f16s",
+NAMES = ["stem_f16s_views", "stem_f16s", "stem", "conv2d_f16s", "conv2d_f16s_pair", "pointwise_split_mfma", "fpn_level", "stage_projections", "offset_heads_f16s",
          "feature_weight", "init_hypotheses", "warp_correlate", "aggregate_regress", "normalize_depth", "conv2d", "refine_fused",
          "confidence", "nchw_to_nhwc"]
 ORIG = {n: getattr(ops, n) for n in NAMES}

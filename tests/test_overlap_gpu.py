@@ -16,7 +16,7 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["stem_f16s", "conv2d_f16s", "pointwise_split_mfma", "fpn_level", "stage_projections", "offset_heads_f16s", "feature_weight",
+NAMES = ["stem_f16s", "conv2d_f16s", "conv2d_f16s_pair", "pointwise_split_mfma", "fpn_level", "stage_projections", "offset_heads_f16s", "feature_weight",
          "init_hypotheses", "warp_correlate", "aggregate_regress", "normalize_depth", "conv2d", "refine_fused", "confidence"]
 
 
@@ -63,11 +63,11 @@ def test_every_launch_is_the_same_beside_the_fp16_mfma_kernels():
     assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
     orig, calls = _capture_forward(1200, 1600, 5)
     names = [c[0] for c in calls]
-    assert names.count("feature_weight") == 3 and names.count("warp_correlate") == 5 and "refine_fused" in names
+    assert names.count("feature_weight") == 3 and names.count("warp_correlate") == 5 and "refine_fused" in names and "conv2d_f16s_pair" in names
     # the two strongest disturbers of round 6's matrix (profiles/r06_overlap/r06_allvictims.log): a 64-channel fp16-split convolution
     # and the fused Refinement kernel
-    conv_calls = [c for c in calls if c[0] == "conv2d_f16s"]
-    disturbers = [conv_calls[3], next(c for c in calls if c[0] == "refine_fused")]
+    conv5 = next(c for c in calls if c[0] == "conv2d_f16s" and c[3][0] is not None and c[3][0].shape[-1] == 32)  # 16 -> 32, 5x5 stride 2
+    disturbers = [conv5, next(c for c in calls if c[0] == "refine_fused")]
     A, B = torch.cuda.Stream(), torch.cuda.Stream()
     reps, failures = 12, []
     with torch.no_grad():
