@@ -50,31 +50,38 @@ def variant(name, fname, edits):
 
 subprocess.check_call(["make", "-s", "-C", CS, "-j8"])
 os.makedirs(OUT, exist_ok=True)
-# fpn_level_kernel: staging writes lane-linear, every operand read lane-linear
-variant("fpn", "conv.hip", [
-    ("*reinterpret_cast<float4*>(xs + pix * XP + 4 * q) = vx[k];", "*reinterpret_cast<float4*>(xs + idx * 4) = vx[k];"),
-    ("if (idx < UPW * UPW * (COUT / 4)) *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) = vu[k];",
-     "if (idx < UPW * UPW * (COUT / 4)) *reinterpret_cast<float4*>(us + idx * 4) = vu[k];"),
-    ("const float4 p00 = *reinterpret_cast<const float4*>(u00 + c0 + c), p01 = *reinterpret_cast<const float4*>(u01 + c0 + c);\n"
-     "                const float4 p10 = *reinterpret_cast<const float4*>(u10 + c0 + c), p11 = *reinterpret_cast<const float4*>(u11 + c0 + c);\n"
-     "                // ATen upsample_bilinear2d: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)\n"
-     "                acc[c] = hy",
-     "const float4 p00 = *reinterpret_cast<const float4*>(us + tid * 4), p01 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 256) & 1023));\n"
-     "                const float4 p10 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 512) & 1023)), p11 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 768) & 1023));\n"
-     "                acc[c] = hy"),
-    ("            const float4 v4 = *reinterpret_cast<const float4*>(xp + ci);\n            const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(ci * COUT + c0);",
-     "            const float4 v4 = *reinterpret_cast<const float4*>(xs + (ci / 4) * 1024 + tid * 4);\n            const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(ci * COUT + c0);"),
-])
-# conv_tiled_kernel: staging writes and operand reads lane-linear
-variant("tiled", "conv.hip", [
-    ("if (idx < ih * iw * CQ) *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v[u];",
-     "if (idx < ih * iw * CQ) *reinterpret_cast<float4*>(tile + idx * 4) = v[u];"),
-    ("const float4 v4 = *reinterpret_cast<const float4*>(tp + 4 * q);\n                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n                    // readfirstlane pins",
-     "const float4 v4 = *reinterpret_cast<const float4*>(tile + ((tid * 4 + q * 1024 + (ky * K + kx) * 64) % (ih * iw * CC)));\n                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n                    // readfirstlane pins"),
-])
-# refine_fused_kernel, phase (2): conv0's 27 scalar reads and the deconvolution's float4 pairs lane-linear
-variant("refine", "refine.hip", [
-    ("const float v = xp[(ci * IR + ky) * IC + kx];", "const float v = xin[((ci * 3 + ky) * 3 + kx) * 64 + lane];"),
-    ("const float4 a = *reinterpret_cast<const float4*>(ip), b = *reinterpret_cast<const float4*>(ip + 4);",
-     "const float4 a = *reinterpret_cast<const float4*>(tp + lane * 8 + (ip - ip)), b = *reinterpret_cast<const float4*>(tp + lane * 8 + 4);"),
-])
+
+
+def main():
+    # fpn_level_kernel: staging writes lane-linear, every operand read lane-linear
+    variant("fpn", "conv.hip", [
+        ("*reinterpret_cast<float4*>(xs + pix * XP + 4 * q) = vx[k];", "*reinterpret_cast<float4*>(xs + idx * 4) = vx[k];"),
+        ("if (idx < UPW * UPW * (COUT / 4)) *reinterpret_cast<float4*>(us + pix * UPP + 4 * q) = vu[k];",
+         "if (idx < UPW * UPW * (COUT / 4)) *reinterpret_cast<float4*>(us + idx * 4) = vu[k];"),
+        ("const float4 p00 = *reinterpret_cast<const float4*>(u00 + c0 + c), p01 = *reinterpret_cast<const float4*>(u01 + c0 + c);\n"
+         "                const float4 p10 = *reinterpret_cast<const float4*>(u10 + c0 + c), p11 = *reinterpret_cast<const float4*>(u11 + c0 + c);\n"
+         "                // ATen upsample_bilinear2d: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)\n"
+         "                acc[c] = hy",
+         "const float4 p00 = *reinterpret_cast<const float4*>(us + tid * 4), p01 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 256) & 1023));\n"
+         "                const float4 p10 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 512) & 1023)), p11 = *reinterpret_cast<const float4*>(us + ((tid * 4 + 768) & 1023));\n"
+         "                acc[c] = hy"),
+        ("            const float4 v4 = *reinterpret_cast<const float4*>(xp + ci);\n            const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(ci * COUT + c0);",
+         "            const float4 v4 = *reinterpret_cast<const float4*>(xs + (ci / 4) * 1024 + tid * 4);\n            const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n            const cfloat* wq = wt + __builtin_amdgcn_readfirstlane(ci * COUT + c0);"),
+    ])
+    # conv_tiled_kernel: staging writes and operand reads lane-linear
+    variant("tiled", "conv.hip", [
+        ("if (idx < ih * iw * CQ) *reinterpret_cast<float4*>(tile + pix * CCP + 4 * q) = v[u];",
+         "if (idx < ih * iw * CQ) *reinterpret_cast<float4*>(tile + idx * 4) = v[u];"),
+        ("const float4 v4 = *reinterpret_cast<const float4*>(tp + 4 * q);\n                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n                    // readfirstlane pins",
+         "const float4 v4 = *reinterpret_cast<const float4*>(tile + ((tid * 4 + q * 1024 + (ky * K + kx) * 64) % (ih * iw * CC)));\n                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};\n                    // readfirstlane pins"),
+    ])
+    # refine_fused_kernel, phase (2): conv0's 27 scalar reads and the deconvolution's float4 pairs lane-linear
+    variant("refine", "refine.hip", [
+        ("const float v = xp[(ci * IR + ky) * IC + kx];", "const float v = xin[((ci * 3 + ky) * 3 + kx) * 64 + lane];"),
+        ("const float4 a = *reinterpret_cast<const float4*>(ip), b = *reinterpret_cast<const float4*>(ip + 4);",
+         "const float4 a = *reinterpret_cast<const float4*>(tp + lane * 8 + (ip - ip)), b = *reinterpret_cast<const float4*>(tp + lane * 8 + 4);"),
+    ])
+
+
+if __name__ == "__main__":
+    main()

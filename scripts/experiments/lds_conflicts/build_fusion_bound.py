@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import build_ablation as BA  # noqa: E402  (builds the LDS variants too when imported: harmless, a few seconds)
+import build_ablation as BA  # noqa: E402
 
 BA.variant("nostore", "conv_f16s.hip", [
     ("                        *reinterpret_cast<f32x4_t*>(po + t * rs + 16 * nt) = v;",
