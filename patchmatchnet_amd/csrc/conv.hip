@@ -515,7 +515,7 @@ __global__ __launch_bounds__(PMN_BLOCK, 2) void fpn_tail_kernel(const float* __r
 #pragma unroll
                 for (int c = 0; c < 16; ++c) s[c] = fmaf(xin[ci], wi[ci * CMID + m0 + cg + c], s[c]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) t[cg + c] = t[cg + c] + (s[c] + bi[m0 + cg + c]);
+            for (int c = 0; c < 16; ++c) t[cg + c] = t[cg + c] + pmn_settle(s[c] + bi[m0 + cg + c]);  // (a scalar sum hipcc packs: lesson 46)
             __builtin_amdgcn_sched_barrier(0);
         }
         // output conv on this half of the intermediate channels

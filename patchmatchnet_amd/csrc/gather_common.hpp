@@ -35,25 +35,7 @@ __device__ __forceinline__ float pmn_pair_swap(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-// ---- lesson 46: packed fp32 math must not read what an LDS load has just written ---------------------------------------------------
-// Measured on MI355X (profiles/r06_overlap/, scripts/overlap_pairs.py, DESIGN_LESSONS.md lesson 46): a v_pk_mul_f32 / v_pk_fma_f32
-// whose source registers were written by a ds_read a few cycles earlier can read their PREVIOUS contents -- for one 16-lane quarter
-// of the wave -- while waves of another kernel on the same CU issue back-to-back v_mfma_f32_16x16x32_f16 (this library's fp16-split
-// convolutions).  Alone, or beside any other kernel, the same code is bit-reproducible, which is why three rounds of single-stream
-// parity tests never saw it and why overlapped forwards differed from the eager forward in "a few thousand pixels' fifth digit"
-// (the stale operand is the previous item's tap weight or similarity: a plausible number).  Plain VALU reads of the same registers are
-// not affected, and neither are packed reads of VMEM-loaded or VALU-written registers.  So every value that goes from LDS into packed
-// math passes through ONE VALU move first: the move reads the LDS-written register safely, the packed instruction reads the move's
-// result.  Same bits, one v_mov per value.  -DPMN_NO_SETTLE restores the direct path (probe builds).
-__device__ __forceinline__ float pmn_settle(float v) {
-#ifndef PMN_NO_SETTLE
-    asm volatile("v_mov_b32 %0, %0" : "+v"(v));
-#endif
-    return v;
-}
-__device__ __forceinline__ float4 pmn_settle4(float4 v) {
-    return make_float4(pmn_settle(v.x), pmn_settle(v.y), pmn_settle(v.z), pmn_settle(v.w));
-}
+// (pmn_settle / pmn_settle4 -- lesson 46's pin for scalars that are broadcast into packed math -- live in pmn_common.hpp)
 
 // Pointwise MLP G -> 16 -> 8 -> 1 for NI items at once, weights read from LDS (uniform address = broadcast read).
 // Layers 1 and 2 are fused in a ROLLED loop over the 16 hidden units: unit j of every item is produced from weight row
@@ -151,7 +133,7 @@ __device__ __forceinline__ void mlp_pairs_from_lds(const float* __restrict__ W, 
     }
     const float4 ta = reinterpret_cast<const float4*>(W + 320)[0], tb = reinterpret_cast<const float4*>(W + 320)[1];
     const float4 wa = reinterpret_cast<const float4*>(W + 328)[0], wb = reinterpret_cast<const float4*>(W + 328)[1];
-    // (read from LDS and used by packed instructions right away: lesson 46)
+    // (scalars out of two float4 loads, broadcast into packed math: lesson 46)
     const float t1[8] = {pmn_settle(ta.x), pmn_settle(ta.y), pmn_settle(ta.z), pmn_settle(ta.w), pmn_settle(tb.x), pmn_settle(tb.y),
                          pmn_settle(tb.z), pmn_settle(tb.w)};
     const float w2[8] = {pmn_settle(wa.x), pmn_settle(wa.y), pmn_settle(wa.z), pmn_settle(wa.w), pmn_settle(wb.x), pmn_settle(wb.y),

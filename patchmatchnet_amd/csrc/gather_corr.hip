@@ -93,6 +93,7 @@ __device__ __forceinline__ PmnCorners load_corners(const char* __restrict__ sbas
 
 template <int LPG, int CG>
 __device__ __forceinline__ float blend_corners(const PmnCorners& c, float4 w4, const float4 refq) {
+    w4 = pmn_settle4(w4);  // scalars of a float4, broadcast into packed math: lesson 46 (gather_common.hpp)
     const pmn_f2 wa = {w4.x, w4.x}, wb = {w4.y, w4.y}, wc = {w4.z, w4.z}, wd = {w4.w, w4.w};
     pmn_f2 lo = pmn_f2{c.t00.x, c.t00.y} * wa;
     pmn_f2 hi = pmn_f2{c.t00.z, c.t00.w} * wa;

@@ -20,6 +20,30 @@
 
 __device__ __forceinline__ float pmn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- lesson 46: no packed fp32 instruction may take its SECOND source's HIGH register for the LOW half of the result ------------------
+// Measured on MI355X (scripts/repro/pk_opsel_matrix.hip, pk_inplace_min.hip; profiles/r06_overlap/r06_pk_opsel_matrix.log): v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 with op_sel:[x,1] / op_sel:[x,1,x] read that operand as ZERO now and then -- for a 16-lane pass -- while
+// waves of another kernel on the same CU issue v_mfma_f32_16x16x32_f16 / _bf16 (this library's fp16-split convolutions).  Alone, or
+// beside any other instruction mix, the same instruction is right two billion times out of two billion, which is why three rounds of
+// single-stream parity tests never saw it and why overlapped forwards differed from the eager forward in "a few thousand pixels' fifth
+// digit".  Every other op_sel / op_sel_hi combination is right beside the same MFMAs.  hipcc emits the form when a scalar that it
+// knows to be the HIGH half of a 64-bit register pair (the .y / .w of an LDS vector load, of a float4 built by DPP moves ...) is
+// broadcast into packed math; a scalar in a register of its own is broadcast with op_sel_hi (low half to both), which is safe.  So
+// every scalar that is broadcast into packed math passes through pmn_settle first: an EMPTY inline asm with the value as a
+// read-write operand -- no instruction; hipcc can no longer see which half of which pair the value came from and gives it a register
+// of its own.  scripts/isa_pk_opsel.py lists the form in a binary; tests/test_isa_hazards.py holds libpmn_hip.so to ZERO sites (the
+// guard proper: the pins are just how this source gets there); tests/test_overlap_gpu.py re-checks every launch beside the MFMA
+// kernels on the device.  -DPMN_NO_SETTLE compiles the pins out (probe builds: the form comes back in ~20 kernels).
+__device__ __forceinline__ float pmn_settle(float v) {
+#ifndef PMN_NO_SETTLE
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+__device__ __forceinline__ float4 pmn_settle4(float4 v) {
+    return make_float4(pmn_settle(v.x), pmn_settle(v.y), pmn_settle(v.z), pmn_settle(v.w));
+}
+
 // ---- bilinear tap set --------------------------------------------------------------------------------------
 // Texel index of the (clamped) north-west corner plus the weights of the 2x2 block anchored there.  Corners that
 // ATen would skip as out of range get weight 0 and a clamped (always legal) address; when the true NW corner is

@@ -1,13 +1,16 @@
 """GPU test for DESIGN_LESSONS.md lesson 46: every kernel launch of a forward must compute the same bits whether it has the device to
 itself or runs beside the kernels that were measured to disturb it.
 
-What round 6 found: while waves of another kernel issue back-to-back v_mfma_f32_16x16x32_f16 on the same CU (this library's fp16-split
-convolutions: pmn_conv2d_f16s, pmn_stem_f16s, pmn_offset_heads_f16s, pmn_refine_fused), a v_pk_*_f32 instruction could read the
-PREVIOUS contents of a register an LDS load had written -- in the three FeatureWeightNet launches (the tap weights) and in the
-PixelwiseNet launch (the MLP's tail constants): 24 of 24 disturbed launches wrong, a few hundred pixels each, which is what made
-overlapped forwards differ from the eager forward for four rounds.  Single-stream parity tests cannot see this class of defect, so
-this test re-issues every captured ops.* call of one forward on stream A while stream B loops the two strongest disturbers, and
-compares with the call's solo output, bit for bit."""
+What round 6 found: on MI355X a v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 whose SECOND source supplies its HIGH register to the LOW
+half of the result (op_sel:[x,1]) reads that operand as zero now and then while waves of another kernel issue
+v_mfma_f32_16x16x32_f16 on the same CU (this library's fp16-split convolutions: pmn_conv2d_f16s, pmn_stem_f16s,
+pmn_offset_heads_f16s, pmn_refine_fused).  hipcc had emitted the form in the three FeatureWeightNet launches (the tap weights), in
+the PixelwiseNet launch (the MLP's tail constants) and in every run-time-bounded gather kernel (non-default hypothesis counts): 24 of
+24 disturbed launches wrong, a few hundred pixels each, which is what made overlapped forwards differ from the eager forward for four
+rounds.  Single-stream parity tests cannot see this class of defect.  The static guard is tests/test_isa_hazards.py (the form must
+not be in the binary); this test is the dynamic one: it re-issues every captured ops.* call of one forward on stream A while stream B
+loops the two strongest disturbers, and compares with the call's solo output, bit for bit -- for the default configuration and for
+the odd hypothesis counts of the "counts" fixture (other kernel instantiations)."""
 import pytest
 import torch
 
@@ -20,10 +23,10 @@ NAMES = ["stem_f16s", "conv2d_f16s", "conv2d_f16s_pair", "pointwise_split_mfma",
          "init_hypotheses", "warp_correlate", "aggregate_regress", "normalize_depth", "conv2d", "refine_fused", "confidence"]
 
 
-def _capture_forward(H, W, n_src):
+def _capture_forward(H, W, n_src, case="default"):
     import patchmatchnet_amd as P
     from patchmatchnet_amd import ops
-    _, params, kw = GU.load_case("default")
+    _, params, kw = GU.load_case(case)
     model = P.PatchmatchNet(**kw)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.cuda().eval()
@@ -59,9 +62,10 @@ def _same(got, want):
     return all(w is None or torch.equal(g, w) for g, w in zip(got, want))
 
 
-def test_every_launch_is_the_same_beside_the_fp16_mfma_kernels():
+@pytest.mark.parametrize("case", ["default", "counts"])
+def test_every_launch_is_the_same_beside_the_fp16_mfma_kernels(case):
     assert torch.cuda.is_available(), "GPU tests selected but no ROCm device is visible"
-    orig, calls = _capture_forward(1200, 1600, 5)
+    orig, calls = _capture_forward(1200, 1600, 5, case)
     names = [c[0] for c in calls]
     assert names.count("feature_weight") == 3 and names.count("warp_correlate") == 5 and "refine_fused" in names and "conv2d_f16s_pair" in names
     # the two strongest disturbers of round 6's matrix (profiles/r06_overlap/r06_allvictims.log): a 64-channel fp16-split convolution
