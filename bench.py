@@ -17,8 +17,8 @@ slots on their own HIP streams, on the runtime's default hardware queues, so tha
 ``--launch graph`` replays HIP graphs instead (rounds 2-5's form; same rate).  ``outputs_verified`` on the line: --verify-steps further
 steps in exactly the timed mode, compared BIT FOR BIT with the same steps launched eagerly one at a time; a mismatch makes the
 process exit non-zero.  (Rounds 2-4 overlapped forwards whose outputs were NOT the eager forward's, round 5 found that out and fell
-back to one hardware queue; round 6 found the cause -- two kernels of this library compute wrong values beside kernels that issue
-dense fp16 MFMAs, DESIGN_LESSONS.md lesson 46 -- and fixed it: overlap is back, verified.)
+back to one hardware queue; round 6 found the cause -- a packed-fp32 instruction form that MI355X computes wrongly beside kernels that
+issue fp16 MFMAs, DESIGN_LESSONS.md lesson 46 -- and removed it from the library: overlap is back, verified.)
 ``--eager`` restores the round-1 mode (one stream, kernels launched from Python); the line always carries that figure too
 (``single_stream_eager`` = one sample's latency).
 

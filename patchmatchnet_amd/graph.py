@@ -306,8 +306,8 @@ class PlannedForward(GraphedForward):
     Why a plan and not the graph: a plan is a page of C (csrc/plan.hip) instead of a runtime feature -- no capture mode, no private
     graph memory pools inside the runtime, no dependence on how a ROCm release replays graphs --, its replay rate is the graph's
     (bench.py --launch graph vs plan: 373-377 vs 376-384 depth-maps/s, round 6) and its contents can be listed (kernel_names()).
-    (Round 5 blamed HIP-graph replay for overlapped forwards that differed from the eager forward; round 6 found the cause in two of
-    this library's own kernels -- DESIGN_LESSONS.md lesson 46 -- and both replay forms are bit-exact on any number of hardware queues
+    (Round 5 blamed HIP-graph replay for overlapped forwards that differed from the eager forward; round 6 found the cause in an
+    instruction form of this library's own gather kernels -- DESIGN_LESSONS.md lesson 46 -- and both replay forms are bit-exact on any number of hardware queues
     since: tests/test_plan_gpu.py, tests/test_overlap_gpu.py, bench.py's outputs_verified.)
 
     What a plan needs from the forward: every launch comes from libpmn_hip.so (the recording pass raises on any other ATen operator,
