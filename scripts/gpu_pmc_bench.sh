@@ -9,7 +9,12 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout 120 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --eager --roofline-steps 4 > $OUT/p$i.log 2>&1)
+  for attempt in 1 2 3; do  # (a pass that crashes or hangs leaves no csv: up to three attempts -- it is the profiler, not the product)
+    rm -rf $OUT/p$i
+    (cd /tmp && timeout 150 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --eager --roofline-steps 4 > $OUT/p$i.log 2>&1)
+    [ -n "$(find $OUT/p$i -name '*counter_collection.csv' 2>/dev/null)" ] && break
+    echo "pass $i ($line): attempt $attempt left no counter file"
+  done
 done <<LIST
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS
@@ -28,6 +33,9 @@ for f in sorted(glob.glob(out+'/p*/*counter_collection.csv')):
 with open(out+'/summary.txt','w') as fo:
     for key,cs in agg.items():
         g=lambda n: (sum(cs[n])/len(cs[n])) if n in cs else 0.0
+        if 'GRBM_GUI_ACTIVE' not in cs or 'SQ_WAVES' not in cs:  # the pass with the denominators failed: no ratios rather than wrong ones
+            line='%-66s (the GRBM_GUI_ACTIVE / SQ_WAVES pass left no counters: ratios not computable)\n'%key
+            print(line,end=''); fo.write(line); continue
         cyc=g('GRBM_GUI_ACTIVE')/8.0
         line='%-66s cyc %8.0f  valu_busy %4.0f%%  valu/wave %6.0f  lds_busy %4.0f%%  lds_conf %4.0f%%  wait_inst %4.0f%%  wait_lds %4.0f%%  mfma/wave %5.0f  mfma16_util %4.0f%%  mfma_busy_raw %10.0f  waves %7.0f\n'%(
             key, cyc, 100*g('SQ_ACTIVE_INST_VALU')*4/1024/max(cyc,1), g('SQ_INSTS_VALU')/max(g('SQ_WAVES'),1),
