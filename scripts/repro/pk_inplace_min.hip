@@ -55,6 +55,7 @@ __device__ __forceinline__ float val(uint32_t a) {  // a small exactly represent
 // FORM 2: v_pk_add_f32 D, A, D op_sel_hi:[1,0]   in place, LOW half broadcast
 // FORM 3: v_pk_fma_f32 D, D, A, C op_sel:[1,0,0] in place on src0, high half broadcast (a form the clean builds also contain)
 // FORM 4: FORM 0 with D loaded from LDS (ds_read_b64) right before
+// FORM 5: FORM 1 behind 16 idle cycles (s_nop 7 twice): is it a forwarding hazard from the VALU instructions that wrote the operands?
 template <int FORM>
 __global__ __launch_bounds__(256) void victim(unsigned long long* errs, int iters) {
     __shared__ f2 lds[256];
@@ -78,6 +79,9 @@ __global__ __launch_bounds__(256) void victim(unsigned long long* errs, int iter
             const f2 C = {1.0f, 2.0f};
             asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,0,0]" : "+v"(D) : "v"(A), "v"(C));
             E = D; e0 = __builtin_fmaf(d1, a0, 1.0f); e1 = __builtin_fmaf(d1, a1, 2.0f);
+        } else if constexpr (FORM == 5) {
+            asm volatile("s_nop 7\n\ts_nop 7\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(E) : "v"(A), "v"(D));
+            e0 = a0 + d1; e1 = a1 + d1;
         } else {
             lds[threadIdx.x] = D;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -116,18 +120,20 @@ int main(int argc, char** argv) {
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    const char* names[5] = {"pk_add in place on src1, hi broadcast (op_sel:[0,1])", "pk_add hi broadcast, not in place", "pk_add in place, lo broadcast",
-                            "pk_fma in place on src0, hi broadcast", "pk_add in place, hi broadcast, operand from LDS"};
+    const char* names[6] = {"pk_add in place on src1, hi broadcast (op_sel:[0,1])", "pk_add hi broadcast, not in place", "pk_add in place, lo broadcast",
+                            "pk_fma in place on src0, hi broadcast", "pk_add in place, hi broadcast, operand from LDS",
+                            "pk_add hi broadcast, not in place, behind 16 idle cycles"};
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) hipLaunchKernelGGL(mfma_loop, dim3(dblocks), dim3(256), 0, sb, d_out, 3000000);
-        unsigned long long e[5];
+        unsigned long long e[6];
         e[0] = run<0>(d_errs, blocks, iters, sa);
         e[1] = run<1>(d_errs, blocks, iters, sa);
         e[2] = run<2>(d_errs, blocks, iters, sa);
         e[3] = run<3>(d_errs, blocks, iters, sa);
         e[4] = run<4>(d_errs, blocks, iters, sa);
+        e[5] = run<5>(d_errs, blocks, iters, sa);
         const bool running = pass == 1 && hipStreamQuery(sb) == hipErrorNotReady;
-        for (int f = 0; f < 5; ++f)
+        for (int f = 0; f < 6; ++f)
             printf("%-18s %-62s wrong results: %llu of %llu\n", pass == 0 ? "alone" : (running ? "beside MFMA loop" : "beside (MFMA ENDED)"), names[f], e[f],
                    (unsigned long long)blocks * 256ull * iters);
         if (pass == 1) CK(hipStreamSynchronize(sb));
