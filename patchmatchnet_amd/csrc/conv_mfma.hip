@@ -220,7 +220,9 @@ extern "C" int pmn_conv2d_mfma(const float* in, const float* weights, const floa
         if (dil != 1) return PMN_ERR_SHAPE;
         // 1x1, 64 -> (ca | cout-ca) <= 128 channels: the 1/8-resolution level of the folded FPN head (pmn_fpn_level's arithmetic)
         if (cin == 64 && K == 1 && stride == 1 && pad == 0 && cout <= 128)
-            return launch_mfma<64, 64, 128, 1, 1, 1, 4, 1, 4, false>(in, weights, shift, out, out_b, a, st);
+            // (the 64 input channels staged in two chunks of 32: 58 us instead of 64 per six 150 x 200 maps, same bits --
+            //  profiles/r06_fpn8_variants.log; 2 or 8 waves per workgroup, chunks of 16, two pixel groups per wave: slower)
+            return launch_mfma<64, 32, 128, 1, 1, 1, 4, 1, 4, false>(in, weights, shift, out, out_b, a, st);
 #ifndef PMN_EXPERIMENTAL
         return PMN_ERR_SHAPE;  // the product library carries the 1x1 form alone (the folded FPN head's 1/8 level)
     }
