@@ -344,7 +344,8 @@ class PlannedForward(GraphedForward):
 
     def _replay(self, handle, dev) -> None:
         from . import _lib
-        _lib.check(_lib.lib().pmn_plan_launch(handle.plan, torch.cuda.current_stream(dev).cuda_stream), "pmn_plan_launch")
+        with torch.cuda.device(dev):  # (plain launches go to the CURRENT device's context: a rank whose device is not the process default)
+            _lib.check(_lib.lib().pmn_plan_launch(handle.plan, torch.cuda.current_stream(dev).cuda_stream), "pmn_plan_launch")
 
 
 class _Plan:
