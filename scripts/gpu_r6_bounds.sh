@@ -2,6 +2,7 @@
 # Upper bounds (ablation builds, wrong results): scripts/experiments/bounds_r6/build_bounds.py -> gpurun_out/r06_bounds.log
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+[ -f build/ldsab/libpmn_hip_stem_skeleton.so ] || python scripts/experiments/bounds_r6/build_bounds.py > /dev/null 2>&1  # (scratch builds are not kept in the tree)
 L=gpurun_out/r06_bounds.log
 : > $L
 P=patchmatchnet_amd/csrc/libpmn_hip.so

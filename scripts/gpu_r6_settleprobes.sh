@@ -3,6 +3,8 @@
 mkdir -p gpurun_out
 L=gpurun_out/r06_settle_probes.log
 : > $L
+[ -f build/wc/libpmn_hip_settle_empty.so ] || bash scripts/build_settle_probes.sh > /dev/null 2>&1  # (scratch builds are not kept in the tree)
+[ -f build/wc/libpmn_hip_nosettle.so ] || bash scripts/build_waitcnt_variants.sh > /dev/null 2>&1
 [ -x build/library_overlap_repro ] || { mkdir -p build; /opt/rocm/bin/hipcc -O2 -o build/library_overlap_repro scripts/repro/library_overlap_repro.cpp -ldl; }
 for i in 1 2; do
   for v in nosettle settle_empty settle_nop settle_copy; do
